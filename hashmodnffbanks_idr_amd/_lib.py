@@ -1,0 +1,77 @@
+"""ctypes loader for libhashmod.so (the C ABI declared in include/hashmod.h).
+
+There is NO fallback: if the library is missing or a call fails, the product raises.
+PyTorch is used only for device memory (``tensor.data_ptr()``) and streams.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libhashmod.so")
+_lib = None
+
+_p = C.c_void_p
+_i64 = C.c_int64
+_int = C.c_int
+
+# name -> (restype, argtypes); must list every symbol include/hashmod.h declares
+SIGNATURES = {
+    "hm_version": (_int, []),
+    "hm_last_error": (C.c_char_p, []),
+    "hm_device_count": (_int, []),
+    "hm_grid_desc_create": (_int, [_int, _int, _p, _p, _p, C.POINTER(_p)]),
+    "hm_grid_desc_destroy": (None, [_p]),
+    "hm_grid_embed_dim": (_int, [_p]),
+    "hm_corner_ids": (_int, [_p, _int, _p, _i64, _p, _p, _p]),
+    "hm_encode_fwd": (_int, [_p, _p, _i64, _p, _p, _p, _i64, _int, _p]),
+    "hm_encode_bwd_table": (_int, [_p, _p, _i64, _p, _i64, _p, _int, _p]),
+}
+
+
+class HashmodError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libhashmod.so; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HashmodError(
+                f"{LIB_PATH} is missing - build it with `python -m hashmodnffbanks_idr_amd.build` "
+                "(hipcc --offload-arch=gfx950); there is no CPU / PyTorch fallback for the hot path")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc < 0:
+        msg = lib().hm_last_error()
+        msg = msg.decode() if msg else "unknown error"
+        if rc == -1:
+            raise ValueError(f"hashmod: {msg}")
+        raise HashmodError(f"hashmod: {msg} (code {rc}) {what}")
+    return rc
+
+
+def stream_ptr(t):
+    """hipStream_t of torch's CURRENT stream on t's device (never the legacy default stream)."""
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def dptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise HashmodError("hashmod: the hot path runs only on HIP (cuda) tensors; got a CPU tensor. "
+                               "There is deliberately no CPU fallback (see oracle/ for the CPU checker).")

@@ -1,0 +1,57 @@
+// hm_common.h - shared host/device definitions for libhashmod (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/hashmod.h"
+
+// Level table handed to kernels BY VALUE (lands in kernarg / SGPRs; no device allocation).
+struct HmLevels {
+    int32_t L;
+    int32_t F;
+    int32_t E;                       // 3 + 2L + L*F
+    int32_t pad_;
+    int32_t res[HM_MAX_LEVELS];
+    uint32_t rows[HM_MAX_LEVELS];
+    uint32_t magic[HM_MAX_LEVELS];   // floor(2^32 / rows) for non power-of-two rows, 0 => use mask
+    uint32_t row_off[HM_MAX_LEVELS]; // first row of the level inside the fused table
+};
+
+struct hm_grid_desc {
+    HmLevels lv;
+    uint64_t total_rows;
+};
+
+void hm_set_error(const std::string &msg);
+int hm_fail(int code, const std::string &msg);
+
+#define HM_CHECK_ARG(cond, msg)                                   \
+    do {                                                          \
+        if (!(cond)) return hm_fail(HM_ERR_INVALID, (msg));       \
+    } while (0)
+
+#define HM_CHECK_LAUNCH(what)                                                                     \
+    do {                                                                                          \
+        hipError_t e__ = hipGetLastError();                                                       \
+        if (e__ != hipSuccess) return hm_fail(HM_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+#ifdef __HIPCC__
+// hash of one voxel corner: reference hashGridEmbedding.py:32-40 restated in uint32
+// (primes 1, 3, 2654435761; xor fold; unsigned modulo by the level's row count).
+__device__ __forceinline__ uint32_t hm_mod_rows(uint32_t h, uint32_t rows, uint32_t magic) {
+    if (magic == 0u) return h & (rows - 1u);  // power of two (also rows == 1)
+    uint32_t q = __umulhi(h, magic);          // q in {floor(h/rows) - 1, floor(h/rows)}
+    uint32_t r = h - q * rows;
+    return r >= rows ? r - rows : r;
+}
+__device__ __forceinline__ uint32_t hm_hash3(uint32_t ux, uint32_t uy, uint32_t uz) {
+    return ux ^ (uy * 3u) ^ (uz * 2654435761u);
+}
+// xi = trunc(x*res): fp32 product, then truncation toward zero (hashGridEmbedding.py:84-85)
+__device__ __forceinline__ int32_t hm_trunc_voxel(float x, int32_t res) {
+    return (int32_t)__fmul_rn(x, (float)res);
+}
+#endif

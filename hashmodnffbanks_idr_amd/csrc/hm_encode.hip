@@ -1,0 +1,336 @@
+// hm_encode.hip - multi-resolution hash-grid encoder kernels for gfx950 (MI355X).
+//
+// Replaces MultiResHashGridMLP.forward / _HashGridMLP.forward / hash_func / FourierFeature.forward
+// (reference: model/embeddings/hashGridEmbedding.py:32-40,81-102,150-155, frequency_enc.py:63-67)
+// and the nn.Embedding backward autograd runs for them.
+//
+// Layout: one fused table [sum(rows_l), F] fp32 in HBM (level l starts at row_off[l]); points
+// x [N,3]; output rows [x | sin | cos | level features], E = 3 + 2L + L*F floats per point.
+//
+// Forward kernel shape (wave64): 8 lanes own one point, one lane per voxel corner, so a single
+// global_load_dwordx2 wave-instruction fetches the 8 corner rows of 8 points; the x/y corner
+// neighbours (hash multipliers 1 and 3) fall into the same 64-B line and coalesce inside the
+// instruction.  The 8-corner weighted sum is a 3-step DPP butterfly (quad_perm, quad_perm,
+// row_half_mirror) - no LDS traffic.  A workgroup (4 waves) owns a tile of 64 points, its waves
+// interleave the levels, and the [64, E] output tile is staged in LDS so that HBM sees only
+// full-line coalesced stores.
+#include "hm_common.h"
+
+#include <math.h>
+
+namespace {
+
+constexpr int kTile = 64;  // points per workgroup
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ float dpp_add_xor1(float v) {
+    int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+    return v + __int_as_float(t);
+}
+__device__ __forceinline__ float dpp_add_xor2(float v) {
+    int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+    return v + __int_as_float(t);
+}
+__device__ __forceinline__ float dpp_add_half_mirror(float v) {
+    int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false);  // row_half_mirror
+    return v + __int_as_float(t);
+}
+
+// corner weight for one axis: reference mode => (bit ? xf : 1-xf) with xf == 0
+template <int FRAC>
+__device__ __forceinline__ void voxel_and_weight(float x, int32_t res, int bit, uint32_t &u, float &w) {
+    float xs = __fmul_rn(x, (float)res);
+    if (FRAC == HM_FRAC_REFERENCE) {
+        int32_t xi = (int32_t)xs;  // trunc toward zero
+        u = (uint32_t)xi + (uint32_t)bit;
+        w = bit ? 0.0f : 1.0f;     // where(mask, 1 - xf, xf) with xf = x - x.float() = 0
+    } else {
+        float fl = floorf(xs);
+        int32_t xi = (int32_t)fl;
+        float xf = __fsub_rn(xs, fl);
+        u = (uint32_t)xi + (uint32_t)bit;
+        w = bit ? xf : __fsub_rn(1.0f, xf);
+    }
+}
+
+template <int FRAC>
+__global__ __launch_bounds__(kThreads) void encode_fwd_f2_kernel(HmLevels lv, const float *__restrict__ x, int64_t n,
+                                                                 const float2 *__restrict__ table,
+                                                                 const float *__restrict__ Bf,
+                                                                 float *__restrict__ out, int64_t out_stride) {
+    extern __shared__ __align__(16) float smem[];
+    const int L = lv.L;
+    const bool fourier = (Bf != nullptr);
+    const int hoff = fourier ? 3 + 2 * L : 0;  // first hash-feature column of an output row
+    const int E = hoff + 2 * L;                // row width written by this launch (F == 2)
+    float *s_out = smem;              // [kTile][E]
+    float *s_x = smem + kTile * E;    // [kTile][3]
+    const int tid = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * kTile;
+    const int cnt = (int)min((int64_t)kTile, n - base);
+
+    if (tid < kTile * 3) {
+        int64_t g = base * 3 + tid;
+        s_x[tid] = (tid < cnt * 3) ? x[g] : 0.0f;
+    }
+    __syncthreads();
+
+    // ---- Fourier features + passthrough: thread -> (point p, channel group cg)
+    if (fourier) {
+        const int p = tid & (kTile - 1);
+        const int cg = tid >> 6;  // 0..3
+        const float x0 = s_x[p * 3 + 0], x1 = s_x[p * 3 + 1], x2 = s_x[p * 3 + 2];
+        float *o = s_out + p * E;
+        if (cg == 0) {
+            o[0] = x0; o[1] = x1; o[2] = x2;
+        }
+        const float two_pi = 6.283185307179586f;  // 2*np.pi*x is evaluated in fp32 (frequency_enc.py:65)
+        const float s0 = __fmul_rn(two_pi, x0), s1 = __fmul_rn(two_pi, x1), s2 = __fmul_rn(two_pi, x2);
+        for (int c = cg; c < L; c += 4) {
+            // [N,3]@[3,L] as a k-ordered fma chain (matches torch's CPU sgemm bit-for-bit, see oracle)
+            float a = __fmul_rn(s0, Bf[c]);
+            a = __fmaf_rn(s1, Bf[L + c], a);
+            a = __fmaf_rn(s2, Bf[2 * L + c], a);
+            float sn, cs;
+            sincosf(a, &sn, &cs);
+            o[3 + c] = sn;
+            o[3 + L + c] = cs;
+        }
+    }
+
+    // ---- hash levels: wave w takes levels w, w+4, ...; lane = (sub-point, corner)
+    {
+        const int wave = tid >> 6;
+        const int lane = tid & 63;
+        const int corner = lane & 7;
+        const int sub = lane >> 3;
+        const int bx = corner & 1, by = (corner >> 1) & 1, bz = (corner >> 2) & 1;
+        for (int l = wave; l < L; l += 4) {
+            const int32_t res = lv.res[l];
+            const uint32_t rows = lv.rows[l], magic = lv.magic[l];
+            const float2 *tl = table + lv.row_off[l];
+            float2 v[8];
+            float w[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int p = j * 8 + sub;
+                uint32_t ux, uy, uz;
+                float wx, wy, wz;
+                voxel_and_weight<FRAC>(s_x[p * 3 + 0], res, bx, ux, wx);
+                voxel_and_weight<FRAC>(s_x[p * 3 + 1], res, by, uy, wy);
+                voxel_and_weight<FRAC>(s_x[p * 3 + 2], res, bz, uz, wz);
+                const uint32_t id = hm_mod_rows(hm_hash3(ux, uy, uz), rows, magic);
+                v[j] = tl[id];
+                w[j] = __fmul_rn(__fmul_rn(wx, wy), wz);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float a0 = __fmul_rn(v[j].x, w[j]);
+                float a1 = __fmul_rn(v[j].y, w[j]);
+                a0 = dpp_add_xor1(a0); a1 = dpp_add_xor1(a1);
+                a0 = dpp_add_xor2(a0); a1 = dpp_add_xor2(a1);
+                a0 = dpp_add_half_mirror(a0); a1 = dpp_add_half_mirror(a1);
+                if (corner == 0) {
+                    const int p = j * 8 + sub;
+                    float *o = s_out + p * E + hoff + 2 * l;
+                    o[0] = a0;
+                    o[1] = a1;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- coalesced tile store
+    if (out_stride == E && (reinterpret_cast<uintptr_t>(out) & 15u) == 0) {
+        float *dst = out + base * E;  // 16-B aligned: kTile*E*4 is a multiple of 16
+        const int total = cnt * E;
+        const int nvec = total >> 2;
+        const float4 *s4 = reinterpret_cast<const float4 *>(s_out);
+        float4 *d4 = reinterpret_cast<float4 *>(dst);
+        for (int i = tid; i < nvec; i += kThreads) d4[i] = s4[i];
+        for (int i = (nvec << 2) + tid; i < total; i += kThreads) dst[i] = s_out[i];
+    } else {
+        for (int i = tid; i < cnt * E; i += kThreads) {
+            int p = i / E, c = i - p * E;
+            out[(base + p) * out_stride + c] = s_out[i];
+        }
+    }
+}
+
+// Generic-F fallback (F != 2): one thread per (point, level); correctness path for unusual configs.
+template <int FRAC>
+__global__ __launch_bounds__(kThreads) void encode_fwd_generic_kernel(HmLevels lv, const float *__restrict__ x,
+                                                                      int64_t n, const float *__restrict__ table,
+                                                                      const float *__restrict__ Bf,
+                                                                      float *__restrict__ out, int64_t out_stride) {
+    const int64_t gid = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int L = lv.L, F = lv.F;
+    const int64_t i = gid / (L + 1);
+    const int l = (int)(gid - i * (L + 1));
+    if (i >= n) return;
+    const float x0 = x[i * 3], x1 = x[i * 3 + 1], x2 = x[i * 3 + 2];
+    float *o = out + i * out_stride;
+    const int hoff = Bf ? 3 + 2 * L : 0;
+    if (l == L) {  // Fourier part
+        if (!Bf) return;
+        o[0] = x0; o[1] = x1; o[2] = x2;
+        const float two_pi = 6.283185307179586f;
+        const float s0 = __fmul_rn(two_pi, x0), s1 = __fmul_rn(two_pi, x1), s2 = __fmul_rn(two_pi, x2);
+        for (int c = 0; c < L; ++c) {
+            float a = __fmul_rn(s0, Bf[c]);
+            a = __fmaf_rn(s1, Bf[L + c], a);
+            a = __fmaf_rn(s2, Bf[2 * L + c], a);
+            float sn, cs;
+            sincosf(a, &sn, &cs);
+            o[3 + c] = sn;
+            o[3 + L + c] = cs;
+        }
+        return;
+    }
+    const float xin[3] = {x0, x1, x2};
+    float acc[8];
+    for (int f = 0; f < F; ++f) acc[f] = 0.0f;
+    for (int c = 0; c < 8; ++c) {
+        uint32_t u[3];
+        float w = 1.0f;
+        for (int d = 0; d < 3; ++d) {
+            float wd;
+            voxel_and_weight<FRAC>(xin[d], lv.res[l], (c >> d) & 1, u[d], wd);
+            w = __fmul_rn(w, wd);
+        }
+        const uint32_t id = hm_mod_rows(hm_hash3(u[0], u[1], u[2]), lv.rows[l], lv.magic[l]);
+        const float *row = table + ((uint64_t)lv.row_off[l] + id) * F;
+        for (int f = 0; f < F; ++f) acc[f] = __fadd_rn(acc[f], __fmul_rn(row[f], w));
+    }
+    for (int f = 0; f < F; ++f) o[hoff + l * F + f] = acc[f];
+}
+
+// xi + 8 corner ids of one level (parity / debugging entry point)
+__global__ __launch_bounds__(kThreads) void corner_ids_kernel(int32_t res, uint32_t rows, uint32_t magic,
+                                                              const float *__restrict__ x, int64_t n,
+                                                              int32_t *__restrict__ xi_out,
+                                                              uint32_t *__restrict__ ids_out) {
+    const int64_t gid = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int64_t i = gid >> 3;
+    const int c = (int)(gid & 7);
+    if (i >= n) return;
+    int32_t xi[3];
+    for (int d = 0; d < 3; ++d) xi[d] = hm_trunc_voxel(x[i * 3 + d], res);
+    if (xi_out && c < 3) xi_out[i * 3 + c] = xi[c];
+    const uint32_t ux = (uint32_t)xi[0] + (c & 1), uy = (uint32_t)xi[1] + ((c >> 1) & 1),
+                   uz = (uint32_t)xi[2] + ((c >> 2) & 1);
+    ids_out[i * 8 + c] = hm_mod_rows(hm_hash3(ux, uy, uz), rows, magic);
+}
+
+// Table gradient: one lane per (point, level, corner); zero-weight corners add nothing and are
+// skipped (in reference mode that leaves exactly one row per point per level).
+template <int FRAC>
+__global__ __launch_bounds__(kThreads) void encode_bwd_table_kernel(HmLevels lv, const float *__restrict__ x,
+                                                                    int64_t n, const float *__restrict__ d_feat,
+                                                                    int64_t d_feat_stride,
+                                                                    float *__restrict__ d_table) {
+    const int L = lv.L, F = lv.F;
+    const int64_t gid = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int c = (int)(gid & 7);
+    const int64_t pl = gid >> 3;
+    const int64_t i = pl / L;
+    const int l = (int)(pl - i * L);
+    if (i >= n) return;
+    uint32_t u[3];
+    float w = 1.0f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float wd;
+        voxel_and_weight<FRAC>(x[i * 3 + d], lv.res[l], (c >> d) & 1, u[d], wd);
+        w = __fmul_rn(w, wd);
+    }
+    if (w == 0.0f) return;
+    const uint32_t id = hm_mod_rows(hm_hash3(u[0], u[1], u[2]), lv.rows[l], lv.magic[l]);
+    const float *g = d_feat + i * d_feat_stride + l * F;
+    float *row = d_table + ((uint64_t)lv.row_off[l] + id) * F;
+    for (int f = 0; f < F; ++f) atomicAdd(row + f, __fmul_rn(w, g[f]));
+}
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+}  // namespace
+
+extern "C" {
+
+int hm_corner_ids(const hm_grid_desc *desc, int level, const float *x, int64_t n, int32_t *xi_out,
+                  uint32_t *ids_out, void *stream) {
+    HM_CHECK_ARG(desc != nullptr, "hm_corner_ids: desc is NULL");
+    HM_CHECK_ARG(level >= 0 && level < desc->lv.L, "hm_corner_ids: level out of range");
+    HM_CHECK_ARG(n >= 0, "hm_corner_ids: n < 0");
+    if (n == 0) return HM_OK;
+    HM_CHECK_ARG(x && ids_out, "hm_corner_ids: NULL pointer");
+    const int64_t threads = n * 8;
+    const unsigned grid = (unsigned)((threads + kThreads - 1) / kThreads);
+    hipLaunchKernelGGL(corner_ids_kernel, dim3(grid), dim3(kThreads), 0, as_stream(stream), desc->lv.res[level],
+                       desc->lv.rows[level], desc->lv.magic[level], x, n, xi_out, ids_out);
+    HM_CHECK_LAUNCH("hm_corner_ids");
+    return HM_OK;
+}
+
+int hm_encode_fwd(const hm_grid_desc *desc, const float *x, int64_t n, const float *table, const float *B_fourier,
+                  float *out, int64_t out_stride, int frac_mode, void *stream) {
+    HM_CHECK_ARG(desc != nullptr, "hm_encode_fwd: desc is NULL");
+    HM_CHECK_ARG(n >= 0, "hm_encode_fwd: n < 0");
+    HM_CHECK_ARG(frac_mode == HM_FRAC_REFERENCE || frac_mode == HM_FRAC_TRILINEAR, "hm_encode_fwd: bad frac_mode");
+    const HmLevels &lv = desc->lv;
+    const int width = B_fourier ? lv.E : lv.L * lv.F;
+    HM_CHECK_ARG(out_stride >= width, "hm_encode_fwd: out_stride < row width");
+    if (n == 0) return HM_OK;
+    HM_CHECK_ARG(x && table && out, "hm_encode_fwd: NULL pointer");
+    if (lv.F == 2) {
+        const int64_t tiles = (n + kTile - 1) / kTile;
+        HM_CHECK_ARG(tiles <= 0x7fffffffLL, "hm_encode_fwd: n too large for one launch");
+        const size_t lds = sizeof(float) * (size_t)(kTile * width + kTile * 3);
+        if (frac_mode == HM_FRAC_REFERENCE)
+            hipLaunchKernelGGL(encode_fwd_f2_kernel<HM_FRAC_REFERENCE>, dim3((unsigned)tiles), dim3(kThreads), lds,
+                               as_stream(stream), lv, x, n, reinterpret_cast<const float2 *>(table), B_fourier, out,
+                               out_stride);
+        else
+            hipLaunchKernelGGL(encode_fwd_f2_kernel<HM_FRAC_TRILINEAR>, dim3((unsigned)tiles), dim3(kThreads), lds,
+                               as_stream(stream), lv, x, n, reinterpret_cast<const float2 *>(table), B_fourier, out,
+                               out_stride);
+    } else {
+        const int64_t threads = n * (lv.L + 1);
+        const int64_t grid = (threads + kThreads - 1) / kThreads;
+        HM_CHECK_ARG(grid <= 0x7fffffffLL, "hm_encode_fwd: n too large for one launch");
+        if (frac_mode == HM_FRAC_REFERENCE)
+            hipLaunchKernelGGL(encode_fwd_generic_kernel<HM_FRAC_REFERENCE>, dim3((unsigned)grid), dim3(kThreads), 0,
+                               as_stream(stream), lv, x, n, table, B_fourier, out, out_stride);
+        else
+            hipLaunchKernelGGL(encode_fwd_generic_kernel<HM_FRAC_TRILINEAR>, dim3((unsigned)grid), dim3(kThreads), 0,
+                               as_stream(stream), lv, x, n, table, B_fourier, out, out_stride);
+    }
+    HM_CHECK_LAUNCH("hm_encode_fwd");
+    return HM_OK;
+}
+
+int hm_encode_bwd_table(const hm_grid_desc *desc, const float *x, int64_t n, const float *d_feat,
+                        int64_t d_feat_stride, float *d_table, int frac_mode, void *stream) {
+    HM_CHECK_ARG(desc != nullptr, "hm_encode_bwd_table: desc is NULL");
+    HM_CHECK_ARG(n >= 0, "hm_encode_bwd_table: n < 0");
+    HM_CHECK_ARG(frac_mode == HM_FRAC_REFERENCE || frac_mode == HM_FRAC_TRILINEAR,
+                 "hm_encode_bwd_table: bad frac_mode");
+    HM_CHECK_ARG(d_feat_stride >= desc->lv.L * desc->lv.F, "hm_encode_bwd_table: d_feat_stride < L*F");
+    if (n == 0) return HM_OK;
+    HM_CHECK_ARG(x && d_feat && d_table, "hm_encode_bwd_table: NULL pointer");
+    const HmLevels &lv = desc->lv;
+    const int64_t threads = n * lv.L * 8;
+    const int64_t grid = (threads + kThreads - 1) / kThreads;
+    HM_CHECK_ARG(grid <= 0x7fffffffLL, "hm_encode_bwd_table: n too large for one launch");
+    if (frac_mode == HM_FRAC_REFERENCE)
+        hipLaunchKernelGGL(encode_bwd_table_kernel<HM_FRAC_REFERENCE>, dim3((unsigned)grid), dim3(kThreads), 0,
+                           as_stream(stream), lv, x, n, d_feat, d_feat_stride, d_table);
+    else
+        hipLaunchKernelGGL(encode_bwd_table_kernel<HM_FRAC_TRILINEAR>, dim3((unsigned)grid), dim3(kThreads), 0,
+                           as_stream(stream), lv, x, n, d_feat, d_feat_stride, d_table);
+    HM_CHECK_LAUNCH("hm_encode_bwd_table");
+    return HM_OK;
+}
+
+}  // extern "C"

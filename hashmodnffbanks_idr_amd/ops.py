@@ -1,0 +1,160 @@
+"""Thin Python operators over the C ABI (include/hashmod.h) + the autograd glue.
+
+Every function here launches hand-written HIP kernels from libhashmod.so on torch's current
+stream; torch supplies device memory only.  CPU tensors raise (no fallback).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, dptr, lib, require_gpu, stream_ptr
+
+FRAC_MODES = {"reference": 0, "trilinear": 1}
+
+
+def level_table(n_levels, log2_hashmap_size, base_resolution, desired_resolution, in_dim=3):
+    """res[l], rows[l] in host double precision, the arithmetic of
+    reference model/embeddings/hashGridEmbedding.py:126-132 (Python ``math``, not fp32)."""
+    beta_growth = math.exp((math.log(desired_resolution) - math.log(base_resolution)) / (n_levels - 1))
+    res, rows = [], []
+    for level_idx in range(n_levels):
+        resolution = math.floor(base_resolution * (beta_growth ** level_idx))
+        res.append(resolution)
+        rows.append(min(resolution ** in_dim, 2 ** log2_hashmap_size))
+    return res, rows
+
+
+class GridDesc:
+    """Owns an hm_grid_desc (host-side level table handed to kernels by value)."""
+
+    def __init__(self, res, rows, n_features=2):
+        self.L = len(res)
+        self.F = int(n_features)
+        self.res = np.asarray(res, np.int32)
+        self.rows = np.asarray(rows, np.uint32)
+        self.row_off = np.concatenate([[0], np.cumsum(self.rows.astype(np.uint64))]).astype(np.uint64)
+        self.total_rows = int(self.row_off[-1])
+        self.E = 3 + 2 * self.L + self.L * self.F
+        self._h = C.c_void_p(0)
+        check(lib().hm_grid_desc_create(self.L, self.F, self.res.ctypes.data_as(C.c_void_p),
+                                        self.rows.ctypes.data_as(C.c_void_p),
+                                        self.row_off.ctypes.data_as(C.c_void_p), C.byref(self._h)))
+
+    @property
+    def handle(self):
+        return self._h
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().hm_grid_desc_destroy(self._h)
+                self._h = C.c_void_p(0)
+        except Exception:
+            pass
+
+
+def _prep_x(x):
+    if x.dtype != torch.float32:
+        x = x.float()
+    return x.reshape(-1, 3).contiguous()
+
+
+def corner_ids(desc, level, x):
+    """xi [N,3] int32 and the 8 corner row ids [N,8] (as int64) of one level - bit-exact with
+    reference hash_func (hashGridEmbedding.py:32-40,84-98)."""
+    x = _prep_x(x)
+    require_gpu(x)
+    n = x.shape[0]
+    xi = torch.empty((n, 3), dtype=torch.int32, device=x.device)
+    ids = torch.empty((n, 8), dtype=torch.int32, device=x.device)
+    check(lib().hm_corner_ids(desc.handle, int(level), dptr(x), n, dptr(xi), dptr(ids), stream_ptr(x)))
+    return xi, ids.long() & 0xFFFFFFFF
+
+
+def encode_fwd(desc, x, table, B, frac_mode=0, hash_only=False):
+    """[N,E] embedding (or [N,L*F] hash features when hash_only) - no autograd."""
+    x = _prep_x(x)
+    require_gpu(x, table, B)
+    assert table.is_contiguous() and table.dtype == torch.float32 and table.shape == (desc.total_rows, desc.F)
+    n = x.shape[0]
+    width = desc.L * desc.F if hash_only else desc.E
+    out = torch.empty((n, width), dtype=torch.float32, device=x.device)
+    Bp = None if hash_only else B.contiguous()
+    check(lib().hm_encode_fwd(desc.handle, dptr(x), n, dptr(table), dptr(Bp), dptr(out), width, int(frac_mode),
+                              stream_ptr(x)))
+    return out
+
+
+def encode_bwd_table(desc, x, d_feat, frac_mode=0, out=None):
+    """Scatter-add of the hash-feature gradient d_feat [N,L*F] into a [rows,F] table gradient."""
+    x = _prep_x(x)
+    require_gpu(x, d_feat)
+    n = x.shape[0]
+    assert d_feat.shape == (n, desc.L * desc.F) and d_feat.dtype == torch.float32
+    if d_feat.stride(1) != 1:
+        d_feat = d_feat.contiguous()
+    if out is None:
+        out = torch.zeros((desc.total_rows, desc.F), dtype=torch.float32, device=x.device)
+    check(lib().hm_encode_bwd_table(desc.handle, dptr(x), n, dptr(d_feat), d_feat.stride(0), dptr(out),
+                                    int(frac_mode), stream_ptr(x)))
+    return out
+
+
+class _HashFeatures(torch.autograd.Function):
+    """Encoder output as an autograd node: hash features [N,L*F] (B is None) or the full
+    [N,E] row [x|sin|cos|features] (B given; only the feature columns carry gradient).
+    Differentiable to any order w.r.t. the table (the op is linear in it).  In reference frac mode
+    d/dx of the hash features is identically zero, exactly as in the reference where
+    xf = x - x.float() kills the interpolation weights (hashGridEmbedding.py:86)."""
+
+    @staticmethod
+    def forward(ctx, x, table, B, desc, frac_mode):
+        ctx.desc, ctx.frac_mode = desc, frac_mode
+        ctx.hoff = 0 if B is None else 3 + 2 * desc.L
+        ctx.save_for_backward(x)
+        return encode_fwd(desc, x, table, B, frac_mode, hash_only=B is None)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (x,) = ctx.saved_tensors
+        d_table = None
+        if ctx.needs_input_grad[1]:
+            d_feat = d_out[:, ctx.hoff:] if ctx.hoff else d_out
+            d_table = _HashScatter.apply(x, d_feat, ctx.desc, ctx.frac_mode)
+        if ctx.needs_input_grad[0]:
+            if ctx.hoff:
+                raise RuntimeError("internal: full-row encode node must not be used when x requires grad")
+            if ctx.frac_mode != 0:
+                raise NotImplementedError("frac_mode='trilinear' has no d/dx kernel yet (non-parity mode)")
+        return None, d_table, None, None, None
+
+
+class _HashScatter(torch.autograd.Function):
+    """d_table = scatter_add(d_feat at x); its own backward is the gather again."""
+
+    @staticmethod
+    def forward(ctx, x, d_feat, desc, frac_mode):
+        ctx.desc, ctx.frac_mode = desc, frac_mode
+        ctx.save_for_backward(x)
+        return encode_bwd_table(desc, x, d_feat, frac_mode)
+
+    @staticmethod
+    def backward(ctx, gg_table):
+        (x,) = ctx.saved_tensors
+        gg = None
+        if ctx.needs_input_grad[1]:
+            gg = _HashFeatures.apply(x, gg_table.contiguous(), None, ctx.desc, ctx.frac_mode)
+        return None, gg, None, None
+
+
+def hash_features(x, table, desc, frac_mode=0):
+    """[N,L*F] hash features with autograd (table grads of any order)."""
+    return _HashFeatures.apply(_prep_x(x), table, None, desc, frac_mode)
+
+
+def encode_table_grad(x, table, B, desc, frac_mode=0):
+    """Full [N,E] embedding in ONE kernel, differentiable w.r.t. the table only (x is a constant)."""
+    return _HashFeatures.apply(_prep_x(x).detach(), table, B, desc, frac_mode)

@@ -1,0 +1,95 @@
+/*
+ * hashmod.h - C ABI of libhashmod.so, the MI355X (gfx950) implementation of the
+ * hash-grid encode / SDF-MLP / sphere-tracing hot path of HashModNFFBanks-IDR.
+ *
+ * This is the drop-in boundary: plain C, raw device pointers and sizes, no torch types.
+ * The reference has no native ABI on its live path (its PyTorch modules call ATen ops);
+ * each entry point below names the reference Python interface it replaces
+ * (paths relative to the reference's code/ directory).
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; hm_last_error() returns a
+ *     thread-local message for the last failing call on this thread (no exceptions cross
+ *     the ABI; the reference reports the same conditions as Python exceptions);
+ *   - the caller owns all memory; pointers are DEVICE pointers unless marked [host];
+ *     nothing is retained after the call returns; workspace is passed in explicitly;
+ *   - `stream` is a hipStream_t (as void*); kernels are launched on it asynchronously and
+ *     the functions never synchronise;  NULL means the HIP default stream;
+ *   - all tensors are fp32, contiguous, row-major unless a stride argument says otherwise;
+ *   - functions are re-entrant; the only mutable global is the error string.
+ */
+#ifndef HASHMOD_H
+#define HASHMOD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define HM_API __attribute__((visibility("default")))
+#else
+#define HM_API
+#endif
+
+#define HM_MAX_LEVELS 32
+#define HM_MAX_LAYERS 16
+
+/* frac_mode */
+#define HM_FRAC_REFERENCE 0 /* reference behaviour: xf = x - x.float() == 0 (hashGridEmbedding.py:86) */
+#define HM_FRAC_TRILINEAR 1 /* build-defined opt-in: floor + fractional weights (NOT a parity mode)    */
+
+#define HM_OK 0
+#define HM_ERR_INVALID (-1) /* bad argument (reference: ValueError / assert)      */
+#define HM_ERR_HIP (-2)     /* HIP runtime / launch failure (reference: RuntimeError) */
+
+HM_API int hm_version(void);
+HM_API const char *hm_last_error(void);
+/* number of HIP devices visible, or <0; never initialises a context */
+HM_API int hm_device_count(void);
+
+/* ---- level table ------------------------------------------------------------------------
+ * Replaces the per-level bookkeeping of MultiResHashGridMLP.__init__
+ * (model/embeddings/hashGridEmbedding.py:106-147): res[l], rows[l] = min(res^3, 2^T) and the
+ * row offset of level l inside the fused [sum(rows), F] table.  The arrays are [host] and are
+ * computed by the caller in double precision exactly as the reference does; the library never
+ * recomputes them.  n_features is F (max_points_per_level).                                   */
+typedef struct hm_grid_desc hm_grid_desc;
+HM_API int hm_grid_desc_create(int n_levels, int n_features, const int32_t *res, const uint32_t *rows,
+                        const uint64_t *row_off /* [n_levels+1] */, hm_grid_desc **out);
+HM_API void hm_grid_desc_destroy(hm_grid_desc *desc);
+HM_API int hm_grid_embed_dim(const hm_grid_desc *desc); /* 3 + 2L + L*F (hashGridEmbedding.py:143-145) */
+
+/* ---- hash indices -----------------------------------------------------------------------
+ * Replaces hash_func + the index half of _HashGridMLP.forward
+ * (hashGridEmbedding.py:32-40, 84-98) for one level: xi = trunc(x*res) and the 8 corner
+ * row ids in bin_mask order.  xi_out [n,3] int32 (may be NULL), ids_out [n,8] uint32.        */
+HM_API int hm_corner_ids(const hm_grid_desc *desc, int level, const float *x, int64_t n, int32_t *xi_out,
+                  uint32_t *ids_out, void *stream);
+
+/* ---- encoder forward --------------------------------------------------------------------
+ * Replaces MultiResHashGridMLP.forward (hashGridEmbedding.py:150-155) including
+ * FourierFeature.forward (frequency_enc.py:63-67):
+ *   out[i] = [ x(3) | sin(2*pi*x@B)(L) | cos(2*pi*x@B)(L) | level features (L*F) ].
+ * x [n,3]; table [sum(rows),F]; B_fourier [3,L]; out rows are out_stride floats apart
+ * (out_stride >= E).  All 8 corners of every level are gathered in both frac modes.
+ * B_fourier == NULL: only the L*F hash-feature columns are produced, out[i*out_stride + l*F + f]
+ * (the torch.cat([level(x) ...]) half of hashGridEmbedding.py:153).                            */
+HM_API int hm_encode_fwd(const hm_grid_desc *desc, const float *x, int64_t n, const float *table,
+                  const float *B_fourier, float *out, int64_t out_stride, int frac_mode, void *stream);
+
+/* ---- encoder backward (table) -----------------------------------------------------------
+ * Replaces the embedding_dense_backward that autograd runs for nn.Embedding in
+ * _HashGridMLP.forward (hashGridEmbedding.py:99-102): d_table[row] += w * d_out.
+ * d_feat points at the hash-feature columns of the upstream gradient: d_feat[i*d_feat_stride + l*F + f]
+ * (for a full [n,E] gradient pass d_out + 3 + 2L and stride E);
+ * d_table [sum(rows),F] is ACCUMULATED into (caller zeroes it, like the reference's
+ * optimizer.zero_grad()).  fp32 atomics: the sum is order-dependent in the last bits.         */
+HM_API int hm_encode_bwd_table(const hm_grid_desc *desc, const float *x, int64_t n, const float *d_feat,
+                        int64_t d_feat_stride, float *d_table, int frac_mode, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HASHMOD_H */

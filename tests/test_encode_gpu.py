@@ -1,0 +1,112 @@
+"""GPU parity of the hash-grid encoder (HIP, through the C ABI) against the golden fixtures
+generated from the reference and against the CPU oracle on larger seeded inputs."""
+import numpy as np
+import pytest
+import torch
+
+import params as P
+from oracle import c_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _embedder(cfg, seed, scale, frac_mode="reference"):
+    from hashmodnffbanks_idr_amd.model.embeddings.hashGridEmbedding import MultiResHashGridMLP
+    L, T, b, d = P.CONFIGS[cfg]
+    emb = MultiResHashGridMLP(True, 3, L, 2, T, b, d, frac_mode=frac_mode).cuda()
+    levels, B, res, rows = P.make_embedder_state(seed, cfg, scale)
+    sd = {f"levels.{l}.embedding.weight": torch.from_numpy(np.ascontiguousarray(t)) for l, t in enumerate(levels)}
+    sd["freq_encoding.B"] = torch.from_numpy(B)
+    emb.load_state_dict(sd)
+    return emb, np.concatenate(levels, 0), B
+
+
+def test_corner_ids_bit_exact(golden):
+    from hashmodnffbanks_idr_amd import ops
+    g = golden("hash_ids")
+    for i, (res, rows) in enumerate(g["combos"]):
+        desc = ops.GridDesc([int(res)], [int(rows)], 2)
+        xi, ids = ops.corner_ids(desc, 0, torch.from_numpy(g[f"x_{i}"]).cuda())
+        assert np.array_equal(xi.cpu().numpy(), g[f"xi_{i}"]), (res, rows)
+        assert np.array_equal(ids.cpu().numpy().astype(np.uint32), g[f"ids_{i}"]), (res, rows)
+
+
+@pytest.mark.parametrize("cfg", ["C1", "C2", "shipped", "viewdir", "tiny"])
+def test_encode_fwd_golden(golden, cfg):
+    g = golden(f"encode_{cfg}")
+    emb, _, _ = _embedder(cfg, int(g["seed"]), float(g["table_scale"]))
+    with torch.no_grad():
+        out = emb(torch.from_numpy(g["x"]).cuda()).cpu().numpy()
+    ref = g["out"]
+    L = P.CONFIGS[cfg][0]
+    nf = 3 + 2 * L
+    assert out.shape == ref.shape
+    assert np.array_equal(out[:, :3], ref[:, :3])
+    assert np.array_equal(out[:, nf:], ref[:, nf:]), "hash features must be bit-exact in reference mode"
+    # Fourier part: tolerance 1e-5 rel fp32 (north star); sin/cos are O(1) so absolute
+    np.testing.assert_allclose(out[:, 3:nf], ref[:, 3:nf], atol=1e-5, rtol=0)
+
+
+@pytest.mark.parametrize("cfg,n", [("C1", 100003), ("C2", 65536 + 17)])
+@pytest.mark.parametrize("frac", ["reference", "trilinear"])
+def test_encode_fwd_vs_oracle_large(cfg, n, frac):
+    emb, table, B = _embedder(cfg, 77, 0.5, frac)
+    L, T, b, d = P.CONFIGS[cfg]
+    x = P.make_points(5, n, -1.3, 1.3)
+    with torch.no_grad():
+        out = emb(torch.from_numpy(x).cuda()).cpu().numpy()
+    ref = O.encode_fwd(O.Grid(L, T, b, d), x, table, B, 0 if frac == "reference" else 1)
+    nf = 3 + 2 * L
+    if frac == "reference":
+        assert np.array_equal(out[:, nf:], ref[:, nf:])
+    else:
+        np.testing.assert_allclose(out[:, nf:], ref[:, nf:], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(out[:, :nf], ref[:, :nf], atol=1e-5, rtol=0)
+
+
+def test_encode_empty_and_ragged():
+    emb, table, B = _embedder("tiny", 3, 0.5)
+    with torch.no_grad():
+        assert emb(torch.zeros((0, 3), device="cuda")).shape == (0, emb.embeddings_dim)
+        for n in (1, 63, 64, 65, 129):
+            x = P.make_points(n, n)
+            out = emb(torch.from_numpy(x).cuda()).cpu().numpy()
+            L, T, b, d = P.CONFIGS["tiny"]
+            ref = O.encode_fwd(O.Grid(L, T, b, d), x, table, B, 0)
+            assert np.array_equal(out[:, 3 + 2 * L:], ref[:, 3 + 2 * L:])
+        # leading batch dims are preserved
+        x = torch.from_numpy(P.make_points(9, 6)).cuda().reshape(2, 3, 3)
+        assert emb(x).shape == (2, 3, emb.embeddings_dim)
+
+
+@pytest.mark.parametrize("cfg", ["C1", "tiny"])
+def test_encode_bwd_table_golden(golden, cfg):
+    g = golden(f"encode_bwd_{cfg}")
+    emb, _, _ = _embedder(cfg, int(g["seed"]), 0.5)
+    x = torch.from_numpy(g["x"]).cuda()
+    y = emb(x)
+    (y * torch.from_numpy(g["d_out"]).cuda()).sum().backward()
+    gt = emb.table.grad.cpu().numpy()
+    nz = np.nonzero(np.abs(gt).sum(1))[0]
+    assert np.array_equal(nz, g["nz_rows"])
+    np.testing.assert_allclose(gt[nz], g["nz_grad"], rtol=1e-5, atol=1e-6)
+
+
+def test_encode_double_backward_linear_in_table():
+    """The scatter's backward is the gather: check <scatter(d), T> == <d, gather(T)>."""
+    from hashmodnffbanks_idr_amd import ops
+    emb, _, _ = _embedder("tiny", 8, 0.5)
+    x = torch.from_numpy(P.make_points(1, 500)).cuda()
+    d = torch.randn(500, emb.n_levels * 2, device="cuda", requires_grad=True)
+    Tt = torch.randn_like(emb.table)
+    s = ops._HashScatter.apply(x, d, emb.desc, 0)
+    (s * Tt).sum().backward()
+    gathered = ops.encode_fwd(emb.desc, x, Tt, None, 0, hash_only=True)
+    np.testing.assert_allclose(d.grad.cpu().numpy(), gathered.cpu().numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_cpu_tensor_fails_loudly():
+    from hashmodnffbanks_idr_amd._lib import HashmodError
+    emb, _, _ = _embedder("tiny", 3, 0.5)
+    with pytest.raises(HashmodError):
+        emb(torch.zeros(4, 3))
