@@ -1,0 +1,349 @@
+// hm_sdf.hip - fused no-grad SDF network forward for gfx950: hash-grid encode + all MLP layers
+// + tanh/Laplace clamp in ONE kernel; activations never leave the CU.
+//
+// Replaces ImplicitNetwork.forward under torch.no_grad()
+// (reference: model/implicit_differentiable_renderer.py:89-113, density_net.py:20-30) - the
+// callable RayTracing evaluates ~123 times per ray.
+//
+// Mapping (MI355X-first, not a GEMM-library call chain):
+//   * a workgroup (8 waves, 512 threads, 1 per CU) owns a tile of 64 points for ALL layers;
+//   * activations live in LDS as X[k/4][point][4] (fp32, 16-B k-groups), 128 KB + the embedding
+//     (kept for the skip connection) 18 KB  -> 146 KB of the CU's 160 KB;
+//   * each layer is D^T[feature, point] = W[feature, k] * X[k, point] on v_mfma_f32_32x32x2_f32
+//     (exact fp32, k-ordered fma chain): W is the A operand streamed straight from L2 into
+//     registers as coalesced 1-KB dwordx4 wave loads of a pre-packed image (each wave owns 64
+//     output features, so weights are never shared between waves and LDS staging would be pure
+//     overhead); X is the B operand read with conflict-free ds_read_b128;
+//   * the accumulator tile has the point on the lane and 4 consecutive features per register
+//     quad, i.e. exactly one 16-B k-group of the NEXT layer: the epilogue (bias, Softplus(100),
+//     optional /sqrt(2)) writes it back with ds_write_b128 - no transpose, no shuffles.
+#include "hm_common.h"
+
+#include <math.h>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kPts = 64;        // points per workgroup tile
+constexpr int kThreadsSdf = 512;
+constexpr int kWaves = 8;
+constexpr int kGroupFloats = kPts * 4;  // floats per k-group row of X: [point][4]
+
+struct SdfNet {  // by value -> kernarg
+    int32_t n_layers;
+    int32_t x_groups;    // k-groups (of 4) in the X region
+    int32_t emb_groups;  // k-groups in the EMB region
+    float beta;          // Laplace density beta = |beta_param| + beta_min
+    hm_mlp_layer layer[HM_MAX_LAYERS];
+};
+
+// nn.Softplus(beta=100, threshold=20): y = x if 100x > 20 else log1p(exp(100x))/100
+// evaluated as max(z,0) + ln(1 + 2^(-|z| log2 e)) with the native exp2/log2 units (abs error < 1e-7
+// before the /100), 8 VALU instructions instead of two libm calls.
+__device__ __forceinline__ float softplus100(float a) {
+    const float z = a * 100.0f;
+    const float t = __builtin_amdgcn_exp2f(-fabsf(z) * 1.4426950408889634f);
+    const float l = __builtin_amdgcn_logf(1.0f + t) * 0.6931471805599453f;  // v_log_f32 is log2
+    const float sp = (fmaxf(z, 0.0f) + l) / 100.0f;
+    return z > 20.0f ? a : sp;
+}
+
+// density_net.py:20-30 + implicit_differentiable_renderer.py:112
+__device__ __forceinline__ float sdf_clamp(float s, float beta) {
+    const float alpha = 1.0f / beta;
+    const float sg = (s > 0.0f) ? 1.0f : ((s < 0.0f) ? -1.0f : 0.0f);
+    const float rho = alpha * (0.5f + 0.5f * sg * expm1f(-fabsf(s) / beta));
+    return tanhf(s / (2.0f + rho));
+}
+
+template <int FRAC>
+__device__ __forceinline__ void corner(float x, int32_t res, int bit, uint32_t &u, float &w) {
+    const float xs = __fmul_rn(x, (float)res);
+    if (FRAC == HM_FRAC_REFERENCE) {
+        u = (uint32_t)((int32_t)xs) + (uint32_t)bit;
+        w = bit ? 0.0f : 1.0f;
+    } else {
+        const float fl = floorf(xs);
+        const float xf = __fsub_rn(xs, fl);
+        u = (uint32_t)((int32_t)fl) + (uint32_t)bit;
+        w = bit ? xf : __fsub_rn(1.0f, xf);
+    }
+}
+
+template <int FRAC>
+__global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_kernel(HmLevels lv, SdfNet net,
+                                                                  const float *__restrict__ x, int64_t n,
+                                                                  const float *__restrict__ table,
+                                                                  const float *__restrict__ Bf,
+                                                                  float *__restrict__ out, int64_t out_stride,
+                                                                  int out_cols) {
+    extern __shared__ __align__(16) float lds[];
+    float *X = lds;
+    float *EMB = lds + (size_t)net.x_groups * kGroupFloats;
+    float *SX = EMB + (size_t)net.emb_groups * kGroupFloats;  // [64][3] raw points
+    float *RED = SX + kPts * 4;                                // [8][64] cross-wave partial sums
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    const int j = lane & 31;  // point within a 32-point tile / feature row within a 32-feature tile
+    const int h = lane >> 5;
+    const int L = lv.L, F = lv.F;
+    const int E = lv.E;
+    const int64_t n_tiles = (n + kPts - 1) / kPts;
+
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t base = tile * kPts;
+        const int cnt = (int)min((int64_t)kPts, n - base);
+        __syncthreads();  // previous tile's output stage is done with X
+        if (tid < kPts * 3) SX[tid] = (tid < cnt * 3) ? x[base * 3 + tid] : 0.0f;
+        __syncthreads();
+
+        // ---------------- encode -> EMB[(e/4)][p][e%4] ------------------------------------
+        {
+            const int p = tid & (kPts - 1);
+            const int grp = tid >> 6;  // 0..7
+            const float x0 = SX[p * 3], x1 = SX[p * 3 + 1], x2 = SX[p * 3 + 2];
+            auto put = [&](int e, float v) { EMB[(e >> 2) * kGroupFloats + p * 4 + (e & 3)] = v; };
+            if (grp == 0) {
+                put(0, x0); put(1, x1); put(2, x2);
+                for (int e = E; e < net.emb_groups * 4; ++e) put(e, 0.0f);  // zero the k padding
+            }
+            const float two_pi = 6.283185307179586f;
+            const float s0 = __fmul_rn(two_pi, x0), s1 = __fmul_rn(two_pi, x1), s2 = __fmul_rn(two_pi, x2);
+            for (int c = grp; c < L; c += kWaves) {
+                float a = __fmul_rn(s0, Bf[c]);
+                a = __fmaf_rn(s1, Bf[L + c], a);
+                a = __fmaf_rn(s2, Bf[2 * L + c], a);
+                float sn, cs;
+                sincosf(a, &sn, &cs);
+                put(3 + c, sn);
+                put(3 + L + c, cs);
+            }
+            for (int l = grp; l < L; l += kWaves) {
+                float acc[8];
+                for (int f = 0; f < F; ++f) acc[f] = 0.0f;
+                const float *tl = table + (size_t)lv.row_off[l] * F;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    uint32_t ux, uy, uz;
+                    float wx, wy, wz;
+                    corner<FRAC>(x0, lv.res[l], c & 1, ux, wx);
+                    corner<FRAC>(x1, lv.res[l], (c >> 1) & 1, uy, wy);
+                    corner<FRAC>(x2, lv.res[l], (c >> 2) & 1, uz, wz);
+                    const float w = __fmul_rn(__fmul_rn(wx, wy), wz);
+                    if (w != 0.0f) {  // zero-weight corners add exactly 0 (reference mode: only corner 0 survives)
+                        const uint32_t id = hm_mod_rows(hm_hash3(ux, uy, uz), lv.rows[l], lv.magic[l]);
+                        for (int f = 0; f < F; ++f) acc[f] = __fadd_rn(acc[f], __fmul_rn(tl[(size_t)id * F + f], w));
+                    }
+                }
+                for (int f = 0; f < F; ++f) put(3 + 2 * L + l * F + f, acc[f]);
+            }
+        }
+        __syncthreads();
+
+        // ---------------- layers ------------------------------------------------------------
+        for (int li = 0; li < net.n_layers; ++li) {
+            const hm_mlp_layer &Ly = net.layer[li];
+            const int n_oct = Ly.seg_octets[0] + Ly.seg_octets[1];
+            if (li == net.n_layers - 1 && out_cols == 1) {
+                // sdf-only: one output feature.  A 32-row MFMA tile would idle 7 of 8 waves for a full
+                // layer time; instead every wave takes a k-slice of the dot product on the VALU
+                // (row 0 of the packed image: tile 0, lanes 0 and 32).
+                const float4 *W0 = reinterpret_cast<const float4 *>(Ly.w_packed);
+                float part = 0.0f;
+                int kg0 = 0;
+                for (int seg = 0; seg < 2; ++seg) {
+                    const float *src = (Ly.seg_src[seg] == 0) ? X : EMB;
+                    const int ng = 2 * Ly.seg_octets[seg];
+                    for (int kg = wave; kg < ng; kg += kWaves) {
+                        const float4 xv = *reinterpret_cast<const float4 *>(src + kg * kGroupFloats + lane * 4);
+                        const int kk = kg0 + kg;
+                        const float4 wv = W0[(size_t)(kk >> 1) * 64 + 32 * (kk & 1)];
+                        part = __fmaf_rn(xv.x, wv.x, part);
+                        part = __fmaf_rn(xv.y, wv.y, part);
+                        part = __fmaf_rn(xv.z, wv.z, part);
+                        part = __fmaf_rn(xv.w, wv.w, part);
+                    }
+                    kg0 += ng;
+                }
+                RED[wave * kPts + lane] = part;
+                __syncthreads();
+                if (tid < cnt) {
+                    float sacc = Ly.bias[0];
+                    for (int w8 = 0; w8 < kWaves; ++w8) sacc += RED[w8 * kPts + tid];
+                    out[(base + tid) * out_stride] = sdf_clamp(sacc, net.beta);
+                }
+                break;
+            }
+            const int nt = Ly.n_tiles;
+            const int t0 = 2 * wave;
+            const int ntw = max(0, min(2, nt - t0));
+            f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+            if (ntw > 0) {
+                const float4 *A0 = reinterpret_cast<const float4 *>(Ly.w_packed) + ((size_t)t0 * n_oct) * 64 + lane;
+                const float4 *A1 = A0 + (ntw > 1 ? (size_t)n_oct * 64 : 0);
+                float4 a0 = A0[0], a1 = A1[0];
+                int gg = 0;
+                for (int seg = 0; seg < 2; ++seg) {
+                    const float *src = (Ly.seg_src[seg] == 0) ? X : EMB;
+                    const int no = Ly.seg_octets[seg];
+                    for (int g = 0; g < no; ++g, ++gg) {
+                        const float4 b0 = *reinterpret_cast<const float4 *>(src + (2 * g + h) * kGroupFloats + j * 4);
+                        const float4 b1 =
+                            *reinterpret_cast<const float4 *>(src + (2 * g + h) * kGroupFloats + (32 + j) * 4);
+                        const int nxt = (gg + 1 < n_oct) ? gg + 1 : gg;
+                        const float4 a0n = A0[(size_t)nxt * 64];
+                        const float4 a1n = A1[(size_t)nxt * 64];
+                        acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc00, 0, 0, 0);
+                        acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b1.x, acc01, 0, 0, 0);
+                        acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, acc10, 0, 0, 0);
+                        acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc11, 0, 0, 0);
+                        acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc00, 0, 0, 0);
+                        acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b1.y, acc01, 0, 0, 0);
+                        acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b0.y, acc10, 0, 0, 0);
+                        acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc11, 0, 0, 0);
+                        acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc00, 0, 0, 0);
+                        acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b1.z, acc01, 0, 0, 0);
+                        acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b0.z, acc10, 0, 0, 0);
+                        acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, acc11, 0, 0, 0);
+                        acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc00, 0, 0, 0);
+                        acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b1.w, acc01, 0, 0, 0);
+                        acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b0.w, acc10, 0, 0, 0);
+                        acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc11, 0, 0, 0);
+                        a0 = a0n;
+                        a1 = a1n;
+                    }
+                }
+            }
+            __syncthreads();  // every wave has finished reading X / EMB for this layer
+
+            // epilogue: registers 4q..4q+3 of a tile = features 8q+4h+{0..3} = one k-group of the next layer
+            const bool act = Ly.activation != 0;
+            const bool div = Ly.post_div_sqrt2 != 0;
+            const float sqrt2 = 1.41421356237309515f;
+            auto store_tile = [&](const f32x16 &acc, int ft, int pt) {
+                const int fbase = 32 * (t0 + ft);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int f = fbase + 8 * q + 4 * h;
+                    const float4 bb = *reinterpret_cast<const float4 *>(Ly.bias + f);
+                    float v0 = acc[4 * q + 0] + bb.x, v1 = acc[4 * q + 1] + bb.y, v2 = acc[4 * q + 2] + bb.z,
+                          v3 = acc[4 * q + 3] + bb.w;
+                    if (act) {
+                        v0 = softplus100(v0); v1 = softplus100(v1); v2 = softplus100(v2); v3 = softplus100(v3);
+                    }
+                    if (div) {
+                        v0 = __fdiv_rn(v0, sqrt2); v1 = __fdiv_rn(v1, sqrt2); v2 = __fdiv_rn(v2, sqrt2);
+                        v3 = __fdiv_rn(v3, sqrt2);
+                    }
+                    *reinterpret_cast<float4 *>(X + (f >> 2) * kGroupFloats + (32 * pt + j) * 4) =
+                        make_float4(v0, v1, v2, v3);
+                }
+            };
+            if (ntw > 0) {
+                store_tile(acc00, 0, 0);
+                store_tile(acc01, 0, 1);
+            }
+            if (ntw > 1) {
+                store_tile(acc10, 1, 0);
+                store_tile(acc11, 1, 1);
+            }
+            if (li == 0 && net.emb_groups > 0) {
+                // the skip layer consumes cat[x, emb]/sqrt(2): rescale the kept embedding once, in place
+                for (int i = tid; i < net.emb_groups * kGroupFloats; i += kThreadsSdf)
+                    EMB[i] = __fdiv_rn(EMB[i], sqrt2);
+            }
+            __syncthreads();
+        }
+
+        // ---------------- output: X[(f/4)][p][f%4] -> out[p][f] -----------------------------
+        const hm_mlp_layer &last = net.layer[net.n_layers - 1];
+        if (out_cols != 1) {
+            const int od = last.out_dim;
+            for (int i = tid; i < cnt * od; i += kThreadsSdf) {
+                const int p = i / od, f = i - p * od;
+                float v = X[(f >> 2) * kGroupFloats + p * 4 + (f & 3)];
+                if (f == 0) v = sdf_clamp(v, net.beta);
+                out[(base + p) * out_stride + f] = v;
+            }
+        }
+    }
+}
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+}  // namespace
+
+extern "C" {
+
+int hm_sdf_fwd(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *x, int64_t n, const float *table,
+               const float *B_fourier, float *out, int64_t out_stride, int out_cols, int frac_mode,
+               int max_workgroups, void *stream) {
+    HM_CHECK_ARG(desc && mlp, "hm_sdf_fwd: NULL descriptor");
+    HM_CHECK_ARG(n >= 0, "hm_sdf_fwd: n < 0");
+    HM_CHECK_ARG(frac_mode == HM_FRAC_REFERENCE || frac_mode == HM_FRAC_TRILINEAR, "hm_sdf_fwd: bad frac_mode");
+    HM_CHECK_ARG(mlp->n_layers >= 1 && mlp->n_layers <= HM_MAX_LAYERS, "hm_sdf_fwd: n_layers out of range");
+    const HmLevels &lv = desc->lv;
+    SdfNet net;
+    net.n_layers = mlp->n_layers;
+    net.beta = mlp->beta;
+    const int emb_oct = (lv.E + 7) / 8;
+    net.emb_groups = emb_oct * 2;
+    int x_groups = 0;
+    for (int l = 0; l < mlp->n_layers; ++l) {
+        const hm_mlp_layer &Ly = mlp->layer[l];
+        HM_CHECK_ARG(Ly.w_packed && Ly.bias, "hm_sdf_fwd: layer has NULL weights/bias");
+        HM_CHECK_ARG(Ly.n_tiles >= 1 && Ly.n_tiles <= 2 * kWaves, "hm_sdf_fwd: layer wider than 512 features");
+        HM_CHECK_ARG(Ly.out_dim >= 1 && Ly.out_dim <= Ly.n_tiles * 32, "hm_sdf_fwd: out_dim / n_tiles mismatch");
+        HM_CHECK_ARG(Ly.seg_octets[0] >= 1 && Ly.seg_octets[1] >= 0, "hm_sdf_fwd: bad segment length");
+        for (int s = 0; s < 2; ++s) {
+            if (Ly.seg_octets[s] == 0) continue;
+            if (Ly.seg_src[s] == 1) {
+                HM_CHECK_ARG(Ly.seg_octets[s] == emb_oct, "hm_sdf_fwd: embedding segment must span ceil(E/8) octets");
+            } else {
+                HM_CHECK_ARG(Ly.seg_src[s] == 0 && l > 0, "hm_sdf_fwd: layer 0 must read the embedding");
+                HM_CHECK_ARG(Ly.seg_octets[s] * 8 <= mlp->layer[l - 1].n_tiles * 32,
+                             "hm_sdf_fwd: layer reads more inputs than the previous layer produces");
+                HM_CHECK_ARG(Ly.seg_octets[s] * 8 >= mlp->layer[l - 1].out_dim,
+                             "hm_sdf_fwd: layer reads fewer inputs than the previous layer produces");
+            }
+        }
+        x_groups = max(x_groups, Ly.n_tiles * 8);
+        net.layer[l] = Ly;
+    }
+    net.x_groups = x_groups;
+    const hm_mlp_layer &last = mlp->layer[mlp->n_layers - 1];
+    HM_CHECK_ARG(out_cols == 1 || out_cols == last.out_dim, "hm_sdf_fwd: out_cols must be 1 or the last layer's out_dim");
+    HM_CHECK_ARG(out_stride >= out_cols, "hm_sdf_fwd: out_stride < out_cols");
+    if (n == 0) return HM_OK;
+    HM_CHECK_ARG(x && table && B_fourier && out, "hm_sdf_fwd: NULL pointer");
+    const size_t lds = sizeof(float) * ((size_t)(net.x_groups + net.emb_groups) * kGroupFloats + kPts * 4 + kWaves * kPts);
+    HM_CHECK_ARG(lds <= 160 * 1024, "hm_sdf_fwd: network does not fit the 160 KB LDS tile");
+    const int64_t tiles = (n + kPts - 1) / kPts;
+    int64_t grid = tiles;
+    const int64_t cap = max_workgroups > 0 ? max_workgroups : 256;
+    if (grid > cap) grid = cap;
+    static thread_local bool attr_done = false;
+    if (!attr_done) {  // opt in to >64 KB dynamic LDS once (not a stream operation)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sdf_fwd_kernel<HM_FRAC_REFERENCE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(sdf_fwd_kernel<HM_FRAC_TRILINEAR>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return hm_fail(HM_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+        attr_done = true;
+    }
+    if (frac_mode == HM_FRAC_REFERENCE) {
+        hipLaunchKernelGGL(sdf_fwd_kernel<HM_FRAC_REFERENCE>, dim3((unsigned)grid), dim3(kThreadsSdf), lds,
+                           as_stream(stream), lv, net, x, n, table, B_fourier, out, out_stride, out_cols);
+    } else {
+        hipLaunchKernelGGL(sdf_fwd_kernel<HM_FRAC_TRILINEAR>, dim3((unsigned)grid), dim3(kThreadsSdf), lds,
+                           as_stream(stream), lv, net, x, n, table, B_fourier, out, out_stride, out_cols);
+    }
+    HM_CHECK_LAUNCH("hm_sdf_fwd");
+    return HM_OK;
+}
+
+}  // extern "C"

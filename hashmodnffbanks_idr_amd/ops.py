@@ -158,3 +158,139 @@ def hash_features(x, table, desc, frac_mode=0):
 def encode_table_grad(x, table, B, desc, frac_mode=0):
     """Full [N,E] embedding in ONE kernel, differentiable w.r.t. the table only (x is a constant)."""
     return _HashFeatures.apply(_prep_x(x).detach(), table, B, desc, frac_mode)
+
+
+# =========================================================================================
+# exact-fp32 MFMA GEMM (csrc/hm_gemm.hip) as an any-order differentiable torch op
+# =========================================================================================
+def gemm(a, b, bias=None, trans_a=False, trans_b=False, out=None, accumulate=False):
+    """C = op(a) @ op(b) (+ bias) on the HIP kernel; no autograd."""
+    require_gpu(a, b, bias)
+    if a.dtype != torch.float32 or b.dtype != torch.float32:
+        raise TypeError("hashmod gemm: fp32 only")
+    if a.stride(-1) != 1:
+        a = a.contiguous()
+    if b.stride(-1) != 1:
+        b = b.contiguous()
+    M, K = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
+    Kb, N = (b.shape[1], b.shape[0]) if trans_b else (b.shape[0], b.shape[1])
+    if K != Kb:
+        raise ValueError(f"hashmod gemm: inner dimensions differ ({K} vs {Kb})")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    if bias is not None:
+        bias = bias.contiguous()
+    check(lib().hm_gemm_f32(int(trans_a), int(trans_b), M, N, K, dptr(a), max(a.stride(0), 1), dptr(b),
+                            max(b.stride(0), 1), dptr(bias), dptr(out), out.stride(0), int(accumulate),
+                            stream_ptr(a)))
+    return out
+
+
+class _MatMul(torch.autograd.Function):
+    """C = op(A) @ op(B) + bias.  backward is expressed with the same op, so autograd can
+    differentiate it again (ImplicitNetwork.gradient uses create_graph=True)."""
+
+    @staticmethod
+    def forward(ctx, a, b, bias, trans_a, trans_b):
+        ctx.ta, ctx.tb = trans_a, trans_b
+        ctx.save_for_backward(a, b)
+        ctx.has_bias = bias is not None
+        return gemm(a, b, bias, trans_a, trans_b)
+
+    @staticmethod
+    def backward(ctx, dc):
+        a, b = ctx.saved_tensors
+        ta, tb = ctx.ta, ctx.tb
+        da = db = dbias = None
+        if ctx.needs_input_grad[0]:
+            # dA' = dC B'^T ; stored layout follows ta
+            da = matmul(b, dc, None, tb, True) if ta else matmul(dc, b, None, False, not tb)
+        if ctx.needs_input_grad[1]:
+            db = matmul(dc, a, None, True, ta) if tb else matmul(a, dc, None, not ta, False)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            dbias = dc.sum(0)
+        return da, db, dbias, None, None
+
+
+def matmul(a, b, bias=None, trans_a=False, trans_b=False):
+    return _MatMul.apply(a, b, bias, trans_a, trans_b)
+
+
+def linear(x, weight, bias=None):
+    """x [N,in] @ weight[out,in]^T + bias - nn.Linear on the HIP GEMM, differentiable to any order."""
+    return _MatMul.apply(x, weight, bias, False, True)
+
+
+# =========================================================================================
+# fused no-grad SDF forward (csrc/hm_sdf.hip)
+# =========================================================================================
+def pack_mlp_layer(W, segs):
+    """Packed MFMA operand image of one folded layer (layout contract: include/hashmod.h).
+
+    W [out, sum(real segment widths)];  segs = [(src, real_width), ...] with src 1 = embedding,
+    0 = previous layer output.  Returns (w_packed, n_tiles, seg_octets, seg_src)."""
+    out_dim = W.shape[0]
+    n_tiles = (out_dim + 31) // 32
+    cols, c0, octs, srcs = [], 0, [], []
+    for src, width in segs:
+        pad = (-width) % 8
+        blk = W[:, c0:c0 + width]
+        if pad:
+            blk = torch.nn.functional.pad(blk, (0, pad))
+        cols.append(blk)
+        octs.append((width + pad) // 8)
+        srcs.append(src)
+        c0 += width
+    assert c0 == W.shape[1]
+    Wp = torch.cat(cols, 1)
+    Wp = torch.nn.functional.pad(Wp, (0, 0, 0, n_tiles * 32 - out_dim))
+    G = Wp.shape[1] // 8
+    Wp = Wp.view(n_tiles, 32, G, 2, 4).permute(0, 2, 3, 1, 4).contiguous()
+    while len(octs) < 2:
+        octs.append(0)
+        srcs.append(0)
+    return Wp, n_tiles, octs, srcs
+
+
+class PackedSdf:
+    """Device-resident packed weights + the [host] hm_mlp_desc for hm_sdf_fwd."""
+
+    def __init__(self, weights, biases, E, skip_in, beta):
+        n = len(weights)
+        self.desc = _lib.MlpDesc()
+        self.desc.n_layers = n
+        self.desc.beta = float(beta)
+        self.keep = []
+        prev_out = None
+        for l in range(n):
+            W = weights[l].detach().float()
+            if l == 0:
+                segs = [(1, E)]
+            elif l in skip_in:
+                segs = [(0, prev_out), (1, E)]
+            else:
+                segs = [(0, prev_out)]
+            Wp, n_tiles, octs, srcs = pack_mlp_layer(W, segs)
+            b = torch.nn.functional.pad(biases[l].detach().float(), (0, n_tiles * 32 - W.shape[0])).contiguous()
+            self.keep += [Wp, b]
+            ly = self.desc.layer[l]
+            ly.w_packed, ly.bias = Wp.data_ptr(), b.data_ptr()
+            ly.out_dim, ly.n_tiles = W.shape[0], n_tiles
+            ly.seg_octets[0], ly.seg_octets[1] = octs[0], octs[1]
+            ly.seg_src[0], ly.seg_src[1] = srcs[0], srcs[1]
+            ly.activation = 1 if l < n - 1 else 0
+            ly.post_div_sqrt2 = 1 if (l + 1) in skip_in else 0
+            prev_out = W.shape[0]
+        self.out_dim = prev_out
+
+
+def sdf_fwd(desc, packed, x, table, B, frac_mode=0, sdf_only=False, max_workgroups=0):
+    """Fused encode + MLP + clamp.  Returns [N] (sdf_only) or [N, out_dim]."""
+    x = _prep_x(x)
+    require_gpu(x, table, B)
+    n = x.shape[0]
+    cols = 1 if sdf_only else packed.out_dim
+    out = torch.empty((n, cols), dtype=torch.float32, device=x.device)
+    check(lib().hm_sdf_fwd(desc.handle, C.byref(packed.desc), dptr(x), n, dptr(table), dptr(B.contiguous()),
+                           dptr(out), cols, cols, int(frac_mode), int(max_workgroups), stream_ptr(x)))
+    return out[:, 0] if sdf_only else out

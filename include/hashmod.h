@@ -89,6 +89,57 @@ HM_API int hm_encode_fwd(const hm_grid_desc *desc, const float *x, int64_t n, co
 HM_API int hm_encode_bwd_table(const hm_grid_desc *desc, const float *x, int64_t n, const float *d_feat,
                         int64_t d_feat_stride, float *d_table, int frac_mode, void *stream);
 
+/* ---- fused SDF network forward (no grad) ---------------------------------------------------
+ * Replaces ImplicitNetwork.forward evaluated under torch.no_grad()
+ * (model/implicit_differentiable_renderer.py:89-113 + density_net.py:20-30), i.e. the `sdf`
+ * callable of RayTracing.forward (model/ray_tracing.py:26-95): embed -> L linear layers with
+ * Softplus(beta=100) -> column 0 through tanh(s / (2 + LaplaceDensity(s))).
+ *
+ * The weight-norm fold W = g*v/||v|| (nn.utils.weight_norm, dim=0) is done by the caller; the
+ * library takes each layer's folded matrix in a packed MFMA operand image:
+ *   K space of a layer = its input segments back to back, each zero-padded to a multiple of 8:
+ *     seg_src 1 = the embedding (E -> ceil(E/8)*8 slots), seg_src 0 = the previous layer's output;
+ *     the skip layer (cat[x, emb]/sqrt(2), :99-100) lists {previous output, embedding}, and the
+ *     layer BEFORE it sets post_div_sqrt2 (the embedding half is rescaled by the kernel);
+ *   rows are zero-padded to n_tiles*32;  n_oct = seg_octets[0] + seg_octets[1];
+ *   w_packed[((u*n_oct + g)*64 + l)*4 + s] = W[32u + (l&31)][8g + 4(l>>5) + s]
+ *     for tile u < n_tiles, octet g < n_oct, lane l < 64, s < 4   (device pointer, 16-B aligned);
+ *   bias: device pointer, n_tiles*32 floats, zero padded, 16-B aligned.
+ * hm_mlp_desc itself is a [host] struct.                                                        */
+typedef struct hm_mlp_layer {
+    const float *w_packed;
+    const float *bias;
+    int32_t out_dim;        /* true number of output features            */
+    int32_t n_tiles;        /* ceil(out_dim/32), at most 16              */
+    int32_t seg_octets[2];  /* K octets per input segment (second may be 0) */
+    int32_t seg_src[2];     /* 0 previous layer output, 1 embedding      */
+    int32_t activation;     /* 1: Softplus(beta=100, threshold=20), 0: none */
+    int32_t post_div_sqrt2; /* 1: outputs are divided by sqrt(2) (feeds the skip concat) */
+} hm_mlp_layer;
+
+typedef struct hm_mlp_desc {
+    int32_t n_layers;
+    float beta; /* LaplaceDensity: |beta_param| + beta_min (density_net.py:28-30) */
+    hm_mlp_layer layer[HM_MAX_LAYERS];
+} hm_mlp_desc;
+
+/* x [n,3] -> out.  out_cols == 1: only the clamped sdf, out[i*out_stride];  out_cols == last
+ * layer's out_dim: the whole [sdf | feature vector] row.  max_workgroups <= 0: one per CU (256). */
+HM_API int hm_sdf_fwd(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *x, int64_t n,
+                      const float *table, const float *B_fourier, float *out, int64_t out_stride, int out_cols,
+                      int frac_mode, int max_workgroups, void *stream);
+
+/* ---- exact-fp32 GEMM (grad-enabled MLP path) ------------------------------------------------
+ * Replaces the nn.Linear matmuls autograd runs for the SDF and rendering MLPs when gradients are
+ * needed (implicit_differentiable_renderer.py:102,116-128,211-221): forward X*W^T + b, backward
+ * dY*W and dY^T*X, and the same shapes again under create_graph=True.
+ *   C[M,N] (+)= op(A)[M,K] * op(B)[K,N] (+ bias[N]);  row-major, leading dimensions in floats;
+ *   transA: A is stored [K,M];  transB: B is stored [N,K];  bias may be NULL;
+ *   accumulate != 0 adds into C (fp32 atomics), otherwise C is overwritten.                      */
+HM_API int hm_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const float *A, int64_t lda,
+                       const float *B, int64_t ldb, const float *bias, float *C, int64_t ldc, int accumulate,
+                       void *stream);
+
 #ifdef __cplusplus
 }
 #endif

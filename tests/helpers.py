@@ -1,0 +1,64 @@
+"""Shared builders for tests: product modules loaded with the seeded parameters of tests/golden/params.py."""
+import numpy as np
+import torch
+
+import params as P
+
+
+class Conf(dict):
+    """pyhocon-like accessor the reference's IDRNetwork(conf) expects (pyhocon is not installed here)."""
+
+    def _g(self, k):
+        d = self
+        for p in k.split("."):
+            d = d[p]
+        return d
+
+    def get_int(self, k):
+        return int(self._g(k))
+
+    def get_float(self, k):
+        return float(self._g(k))
+
+    def get_config(self, k):
+        v = self.get(k)
+        return Conf(v) if v is not None else None
+
+
+def idr_conf(cfg, hidden=(512,) * 8, fvs=256, rdims=(512,) * 4):
+    L, Tt, b, d = P.CONFIGS[cfg]
+    return Conf(
+        feature_vector_size=fvs,
+        implicit_network=dict(d_in=3, d_out=1, dims=list(hidden), geometric_init=True, bias=0.6, skip_in=[4],
+                              weight_norm=True, multires=L),
+        rendering_network=dict(mode="idr", d_in=9, d_out=3, viewdirs_embed_type="HashGrid", dims=list(rdims),
+                               weight_norm=True, multires_view=4),
+        ray_tracer=dict(object_bounding_sphere=1.0, sdf_threshold=5.0e-5, line_search_step=0.5, line_step_iters=3,
+                        sphere_tracing_iters=10, n_steps=100, n_secant_steps=8),
+        embedding_network=dict(embed_type="HashGrid", log2_max_hash_size=Tt, max_points_per_entry=2,
+                               base_resolution=b, desired_resolution=d, bound=1.0),
+    )
+
+
+def load_embedder(emb, levels, B):
+    sd = {f"levels.{l}.embedding.weight": torch.from_numpy(np.ascontiguousarray(t)) for l, t in enumerate(levels)}
+    sd["freq_encoding.B"] = torch.from_numpy(B)
+    emb.load_state_dict(sd)
+
+
+def make_implicit(cfg, hidden, fvs, seed, perturb, table_scale, g_jitter=0.1, device="cuda"):
+    from hashmodnffbanks_idr_amd.model.implicit_differentiable_renderer import ImplicitNetwork
+    L, Tt, b, d = P.CONFIGS[cfg]
+    net = ImplicitNetwork(fvs, 3, 1, list(hidden), True, 0.6, [4], True, multires=L, embed_type="HashGrid",
+                          log2_max_hash_size=Tt, max_points_per_entry=2, base_resolution=b, desired_resolution=d,
+                          bound=1.0)
+    levels, B, res, rows = P.make_embedder_state(seed, cfg, table_scale)
+    load_embedder(net.embed_model.embedder_obj, levels, B)
+    E = 3 + 4 * L
+    prm = P.make_sdf_params(seed + 7, E, hidden, 1 + fvs, (4,), 0.6, perturb, g_jitter)
+    sd = net.state_dict()
+    for k, v in prm.items():
+        assert sd[k].shape == v.shape, (k, sd[k].shape, v.shape)
+        sd[k] = torch.from_numpy(v)
+    net.load_state_dict(sd)
+    return net.to(device)

@@ -1,0 +1,150 @@
+"""GPU parity of the SDF network: fused no-grad kernel, GEMM autograd path, gradient() and the
+eikonal double backward, against fixtures generated from the reference."""
+import numpy as np
+import pytest
+import torch
+
+import params as P
+from helpers import make_implicit
+from oracle import c_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("full", "C1"), ("init", "C1"), ("narrow", "tiny")]
+
+
+def _net(g, cfg):
+    return make_implicit(cfg, tuple(g["hidden"].tolist()), int(g["fvs"]), int(g["seed"]), float(g["perturb"]),
+                         float(g["table_scale"]))
+
+
+def _close(a, b, rtol=1e-5, atol=2e-6, what=""):
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, err_msg=what)
+
+
+@pytest.mark.parametrize("tag,cfg", CASES)
+def test_fused_forward_golden(golden, tag, cfg):
+    g = golden(f"sdf_{tag}")
+    net = _net(g, cfg)
+    x = torch.from_numpy(g["x"]).cuda()
+    with torch.no_grad():
+        out = net(x)
+        sdf = net.sdf(x)
+    _close(out.cpu().numpy(), g["out"], what="fused full output")
+    _close(sdf.cpu().numpy(), g["out"][:, 0], what="fused sdf-only output")
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 64 * 300 + 5])
+def test_fused_forward_vs_oracle_ragged(golden, n):
+    g = golden("sdf_full")
+    net = _net(g, "C1")
+    L, T, b, d = P.CONFIGS["C1"]
+    seed = int(g["seed"])
+    levels, B, _, _ = P.make_embedder_state(seed, "C1", float(g["table_scale"]))
+    prm = P.make_sdf_params(seed + 7, 3 + 4 * L, (512,) * 8, 257, (4,), 0.6, float(g["perturb"]), 0.1)
+    orc = O.SdfOracle(O.Grid(L, T, b, d), np.concatenate(levels, 0), B, prm)
+    x = P.make_points(n + 1, n, -1.05, 1.05)
+    with torch.no_grad():
+        sdf = net.sdf(torch.from_numpy(x).cuda()).cpu().numpy()
+        full = net(torch.from_numpy(x[:200]).cuda()).cpu().numpy() if n >= 200 else None
+    ref = orc(x)
+    _close(sdf, ref[:, 0], what="sdf-only vs oracle")
+    if full is not None:
+        _close(full, ref[:200], what="full vs oracle")
+
+
+@pytest.mark.parametrize("tag,cfg", CASES)
+def test_grad_path_forward_and_first_order(golden, tag, cfg):
+    g = golden(f"sdf_{tag}")
+    net = _net(g, cfg)
+    net.train()
+    x = torch.from_numpy(g["x"].copy()).cuda().requires_grad_(True)
+    out = net(x)
+    _close(out.detach().cpu().numpy(), g["out"], what="grad-path forward")
+    (out * torch.from_numpy(g["R"]).cuda()).sum().backward()
+    _close(x.grad.cpu().numpy(), g["dx_first"], rtol=2e-5, atol=1e-5, what="d/dx")
+    _check_param_grads(net, g, "g1")
+
+
+def _check_param_grads(net, g, label):
+    emb = net.embed_model.embedder_obj
+    off = emb.desc.row_off
+    for name, p in net.named_parameters():
+        if p.grad is None:
+            continue
+        arr = p.grad.detach().cpu().numpy()
+        if name.endswith("embedder_obj.table"):
+            for l in range(emb.n_levels):
+                _cmp(arr[int(off[l]):int(off[l + 1])], g, f"{label}:table{l}")
+        else:
+            _cmp(arr, g, f"{label}:{name}")
+
+
+def _cmp(arr, g, key):
+    ref_norm = float(g[key + ":norm"])
+    got_norm = float(np.linalg.norm(arr.astype(np.float64)))
+    assert abs(got_norm - ref_norm) <= 1e-4 * max(ref_norm, 1e-12) + 1e-9, (key, got_norm, ref_norm)
+    scale = max(ref_norm / np.sqrt(arr.size), 1e-12)
+    if key + ":full" in g.files:
+        ref = g[key + ":full"]
+        np.testing.assert_allclose(arr, ref, rtol=1e-4, atol=2e-4 * max(np.abs(ref).max(), scale), err_msg=key)
+    else:
+        idx = g[key + ":idx"]
+        ref = g[key + ":val"]
+        np.testing.assert_allclose(arr.reshape(-1)[idx], ref, rtol=1e-4, atol=2e-4 * max(np.abs(ref).max(), scale),
+                                   err_msg=key)
+
+
+@pytest.mark.parametrize("tag,cfg", CASES)
+def test_gradient_and_eikonal_double_backward(golden, tag, cfg):
+    g = golden(f"sdf_{tag}")
+    net = _net(g, cfg)
+    net.train()
+    x = torch.from_numpy(g["x"].copy()).cuda()
+    gr = net.gradient(x)
+    assert gr.shape == (x.shape[0], 1, 3)
+    _close(gr.detach().cpu().numpy()[:, 0, :], g["gradient"], rtol=2e-5, atol=1e-5, what="gradient()")
+    eik = ((gr[:, 0, :].norm(2, dim=1) - 1) ** 2).mean()
+    assert abs(eik.item() - float(g["eik"])) <= 1e-5 * abs(float(g["eik"])) + 1e-7
+    eik.backward()
+    _check_param_grads(net, g, "g2")
+
+
+def test_gemm_shapes_vs_torch():
+    from hashmodnffbanks_idr_amd import ops
+    rs = np.random.RandomState(0)
+    for (M, N, K) in [(1, 1, 1), (100, 445, 67), (300, 257, 512), (64, 64, 16), (513, 130, 33), (2048, 512, 512)]:
+        a = torch.from_numpy(rs.standard_normal((M, K)).astype(np.float32)).cuda()
+        b = torch.from_numpy(rs.standard_normal((K, N)).astype(np.float32)).cuda()
+        bias = torch.from_numpy(rs.standard_normal(N).astype(np.float32)).cuda()
+        ref = (a.double() @ b.double() + bias.double()).float()
+        tol = dict(rtol=1e-5, atol=2e-5 * np.sqrt(K))
+        np.testing.assert_allclose(ops.gemm(a, b, bias).cpu(), ref.cpu(), **tol)
+        np.testing.assert_allclose(ops.gemm(a.t().contiguous(), b, bias, trans_a=True).cpu(), ref.cpu(), **tol)
+        np.testing.assert_allclose(ops.gemm(a, b.t().contiguous(), bias, trans_b=True).cpu(), ref.cpu(), **tol)
+        np.testing.assert_allclose(ops.gemm(a.t().contiguous(), b.t().contiguous(), bias, True, True).cpu(),
+                                   ref.cpu(), **tol)
+    # split-K shape of the weight gradient: small M x N, long K
+    a = torch.from_numpy(rs.standard_normal((6000, 512)).astype(np.float32)).cuda()
+    b = torch.from_numpy(rs.standard_normal((6000, 445)).astype(np.float32)).cuda()
+    ref = (a.double().t() @ b.double()).float()
+    np.testing.assert_allclose(ops.gemm(a, b, None, trans_a=True).cpu(), ref.cpu(), rtol=1e-5, atol=2e-3)
+
+
+def test_matmul_double_backward_vs_torch():
+    from hashmodnffbanks_idr_amd import ops
+    torch.manual_seed(0)
+    x = torch.randn(37, 19, device="cuda", requires_grad=True)
+    w = torch.randn(23, 19, device="cuda", requires_grad=True)
+    b = torch.randn(23, device="cuda", requires_grad=True)
+
+    def run(lin):
+        y = torch.tanh(lin(x, w, b))
+        (gx,) = torch.autograd.grad(y.sum(), x, create_graph=True)
+        loss = (gx ** 2).sum() + y.pow(2).sum()
+        return torch.autograd.grad(loss, [x, w, b])
+
+    got = run(ops.linear)
+    ref = run(torch.nn.functional.linear)
+    for a_, b_ in zip(got, ref):
+        np.testing.assert_allclose(a_.cpu().numpy(), b_.cpu().numpy(), rtol=1e-4, atol=1e-4)
