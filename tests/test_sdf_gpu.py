@@ -62,7 +62,9 @@ def test_grad_path_forward_and_first_order(golden, tag, cfg):
     out = net(x)
     _close(out.detach().cpu().numpy(), g["out"], what="grad-path forward")
     (out * torch.from_numpy(g["R"]).cuda()).sum().backward()
-    _close(x.grad.cpu().numpy(), g["dx_first"], rtol=2e-5, atol=1e-5, what="d/dx")
+    # d/dx sums ~257 signed terms: tolerance relative to the gradient's scale, not per element
+    _close(x.grad.cpu().numpy(), g["dx_first"], rtol=2e-5, atol=1e-5 * float(np.abs(g["dx_first"]).max()),
+           what="d/dx")
     _check_param_grads(net, g, "g1")
 
 
