@@ -2,17 +2,22 @@
 """bench.py - rays/sec fwd+bwd (hash + SDF MLP) and hash-gather HBM GB/s on MI355X.
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W   -> ONE JSON line on rank 0.
-For N>1 it is launched by torch.distributed.run, one rank per GPU (RCCL).
+For N>1 it is launched by torch.distributed.run, one rank per GPU (RCCL over xGMI).
 
-A "step" = one pass of the hot path over one batch of synthetic uniform-sphere rays
-(SURVEY.md section 8d): IDRNetwork.forward (sphere tracing + SDF/rendering MLPs) + IDRLoss +
-backward (+ gradient all-reduce when N>1).  Workload = BASELINE.json configs[1]:
-MultiResHash L=16 T=2^19 F=2, 2048 rays per GPU, fp32.
+A "step" = one training iteration of the hot path on one batch of synthetic uniform-sphere rays
+(SURVEY.md section 8d), in the reference runner's order (idr_train.py:294-308):
+IDRNetwork.forward (sphere tracing with the fused SDF kernel, grad-enabled SDF / rendering MLPs,
+gradient() with create_graph) + IDRLoss + backward + [gradient all-reduce] + clip_grad_norm_ + Adam.
+Workload = BASELINE.json configs[1]: MultiResHash L=16 T=2^19 F=2, 2048 rays PER GPU (weak
+scaling), fp32, geometric-init weights seed 0, object_mask all true, rgb_gt = 0.
 
 Extra objects on the same line:
-  roofline     - the hash-gather kernel (BASELINE metric "hash-gather HBM GB/s"): algorithmic
-                 bytes (1304 B/point at L=16,F=2) x 2^22 points / HIP-event time per launch
-  cpu_baseline - the C oracle (oracle/hm_oracle.c, a port) timed on the host cores
+  roofline      hash-gather kernel (BASELINE metric "hash-gather HBM GB/s"): algorithmic bytes
+                (1304 B/point at L=16,F=2) x 2^22 points / HIP-event time per launch
+  roofline_mlp  fused SDF forward kernel (the kernel that dominates the step): 3.93 MFLOP/point
+                against the 157.3 TFLOP/s fp32 MFMA peak
+  cpu_baseline  oracle/torch_ref.py (a port: the reference's op sequence on torch-CPU) timed on
+                the host cores on a bounded sample of the same workload
 """
 import argparse
 import json
@@ -21,7 +26,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "tests", "golden")):
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
@@ -30,7 +35,67 @@ import torch  # noqa: E402
 
 import params as P  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
+SDF_MAC_PER_POINT = 1966592  # SURVEY.md 8a row A9 (independent of the embedding width)
+RAYS_PER_GPU = 2048
+CFG = "C2"
+
+
+class Conf(dict):
+    def _g(self, k):
+        d = self
+        for p in k.split("."):
+            d = d[p]
+        return d
+
+    def get_int(self, k):
+        return int(self._g(k))
+
+    def get_float(self, k):
+        return float(self._g(k))
+
+    def get_config(self, k):
+        v = self.get(k)
+        return Conf(v) if v is not None else None
+
+
+def idr_conf(cfg):
+    """confs/embedder_conf_var/MultiResHashPointsAndViewDirs/dtu_fixed_cameras.conf with the
+    embedding_network block of BASELINE.json's config."""
+    L, T, b, d = P.CONFIGS[cfg]
+    return Conf(
+        feature_vector_size=256,
+        implicit_network=dict(d_in=3, d_out=1, dims=[512] * 8, geometric_init=True, bias=0.6, skip_in=[4],
+                              weight_norm=True, multires=L),
+        rendering_network=dict(mode="idr", d_in=9, d_out=3, viewdirs_embed_type="HashGrid", dims=[512] * 4,
+                               weight_norm=True, multires_view=4),
+        ray_tracer=dict(object_bounding_sphere=1.0, sdf_threshold=5.0e-5, line_search_step=0.5, line_step_iters=3,
+                        sphere_tracing_iters=10, n_steps=100, n_secant_steps=8),
+        embedding_network=dict(embed_type="HashGrid", log2_max_hash_size=T, max_points_per_entry=2,
+                               base_resolution=b, desired_resolution=d, bound=1.0),
+    )
+
+
+def synthetic_batch(seed, n_rays, device):
+    """Uniform-sphere rays through an identity-K pinhole (uv reproduce the directions exactly enough)."""
+    cam, dirs = P.make_rays(seed, n_rays)
+    z = -cam[0] / np.linalg.norm(cam[0])
+    up = np.array([0.0, 1.0, 0.0])
+    xax = np.cross(up, z)
+    xax /= np.linalg.norm(xax)
+    yax = np.cross(z, xax)
+    R = np.stack([xax, yax, z], 1)
+    pose = np.eye(4, dtype=np.float32)
+    pose[:3, :3] = R
+    pose[:3, 3] = cam[0]
+    dc = dirs[0].astype(np.float64) @ R
+    uv = (dc[:, :2] / dc[:, 2:3]).astype(np.float32).reshape(1, n_rays, 2)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)  # noqa: E731
+    inp = dict(intrinsics=T(np.eye(4, dtype=np.float32).reshape(1, 4, 4)), uv=T(uv), pose=T(pose.reshape(1, 4, 4)),
+               object_mask=torch.ones((1, n_rays), dtype=torch.bool, device=device))
+    gt = dict(rgb=torch.zeros((1, n_rays, 3), dtype=torch.float32, device=device))
+    return inp, gt
 
 
 def gather_bytes_per_point(L, F):
@@ -38,65 +103,89 @@ def gather_bytes_per_point(L, F):
     return 12 + L * 8 * F * 4 + (3 + 2 * L + L * F) * 4
 
 
-def build_embedder(cfg, device, seed=0):
-    from hashmodnffbanks_idr_amd.model.embeddings.hashGridEmbedding import MultiResHashGridMLP
-    L, T, b, d = P.CONFIGS[cfg]
-    emb = MultiResHashGridMLP(True, 3, L, 2, T, b, d).to(device)
-    g = torch.Generator(device="cpu").manual_seed(seed)
-    with torch.no_grad():
-        emb.table.copy_((torch.rand(emb.table.shape, generator=g) * 2e-4 - 1e-4).to(device))
-    return emb
-
-
-def gather_roofline(cfg="C2", log2_n=22, iters=10, warmup=3, device="cuda:0"):
+def gather_roofline(emb, log2_n=22, iters=10, warmup=3):
     """HIP-event timing of hm_encode_fwd on torch's current stream (the stream the kernel runs on)."""
     from hashmodnffbanks_idr_amd import ops
-    L, T, b, d = P.CONFIGS[cfg]
-    emb = build_embedder(cfg, device)
+    dev = emb.table.device
     n = 1 << log2_n
     g = torch.Generator(device="cpu").manual_seed(1234)
-    x = (torch.rand((n, 3), generator=g) * 2 - 1).to(device)
-    out = None
+    x = (torch.rand((n, 3), generator=g) * 2 - 1).to(dev)
+    table, B = emb.table.detach(), emb.freq_encoding.B
     for _ in range(warmup):
-        out = ops.encode_fwd(emb.desc, x, emb.table.detach(), emb.freq_encoding.B, 0)
+        out = ops.encode_fwd(emb.desc, x, table, B, 0)
     torch.cuda.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
     for s, e in evs:
         s.record()
-        out = ops.encode_fwd(emb.desc, x, emb.table.detach(), emb.freq_encoding.B, 0)
+        out = ops.encode_fwd(emb.desc, x, table, B, 0)
         e.record()
     torch.cuda.synchronize()
-    ms = np.asarray([s.elapsed_time(e) for s, e in evs])
     del out
-    bpp = gather_bytes_per_point(L, 2)
+    ms = np.asarray([s.elapsed_time(e) for s, e in evs])
+    bpp = gather_bytes_per_point(emb.n_levels, emb.n_features)
     avg_ms = float(ms.mean())
     achieved = n * bpp / (avg_ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-            "kernel": "encode_fwd_f2_kernel", "points": n, "bytes_per_point": bpp,
-            "avg_launch_ms": round(avg_ms, 4), "min_launch_ms": round(float(ms.min()), 4),
-            "workload": f"{cfg}: L={L} T=2^{T} F=2, N=2^{log2_n} points U([-1,1]^3), table "
-                        f"{emb.table.numel() * 4 / 2**20:.1f} MiB (cache-resident below 256 MiB)"}
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "encode_fwd_f2_kernel",
+            "units_per_launch": n, "bytes_per_unit": bpp, "avg_launch_ms": round(avg_ms, 4),
+            "min_launch_ms": round(float(ms.min()), 4),
+            "note": f"table {emb.table.numel() * 4 / 2**20:.1f} MiB is Infinity-Cache resident (<256 MiB)"}
 
 
-def cpu_baseline_gather(cfg="C2", n=1 << 18):
-    """The C oracle (port) on the host cores, same synthetic inputs, bounded sample."""
-    from oracle import c_oracle as O
-    L, T, b, d = P.CONFIGS[cfg]
-    grid = O.Grid(L, T, b, d)
-    rs = np.random.RandomState(0)
-    table = rs.uniform(-1e-4, 1e-4, (grid.total_rows, 2)).astype(np.float32)
-    B = P.make_fourier_B(1, L, P.fourier_sigma(b, d))
-    x = P.make_points(1234, n)
-    O.encode_fwd(grid, x[:1024], table, B, 0)
+def mlp_roofline(net, log2_n=18, iters=5, warmup=2):
+    """Fused SDF forward (encode + 9 MFMA layers), sdf-only output: 2*1 966 592 flop per point."""
+    dev = next(net.parameters()).device
+    n = 1 << log2_n
+    g = torch.Generator(device="cpu").manual_seed(99)
+    x = (torch.rand((n, 3), generator=g) * 2 - 1).to(dev)
+    for _ in range(warmup):
+        net.sdf(x)
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for s, e in evs:
+        s.record()
+        net.sdf(x)
+        e.record()
+    torch.cuda.synchronize()
+    ms = np.asarray([s.elapsed_time(e) for s, e in evs])
+    avg_ms = float(ms.mean())
+    flops = 2.0 * (SDF_MAC_PER_POINT - 512 * 256)  # sdf-only: the 256 feature rows of the last layer are skipped
+    tf = n * flops / (avg_ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+            "frac": round(tf / MFMA_F32_PEAK_TF, 4), "traffic": None, "kernel": "sdf_fwd_kernel",
+            "units_per_launch": n, "flop_per_unit": flops, "avg_launch_ms": round(avg_ms, 4),
+            "points_per_s": round(n / (avg_ms * 1e-3), 1)}
+
+
+def cpu_baseline(n_rays=256, reps=2):
+    """oracle/torch_ref.py (port of the reference's PyTorch path) on the host cores, same workload
+    shape at a bounded ray count: forward + IDRLoss + backward."""
+    from oracle import torch_ref as R
+    from hashmodnffbanks_idr_amd.model.implicit_differentiable_renderer import IDRNetwork
+    from hashmodnffbanks_idr_amd.model.loss import IDRLoss
+    torch.manual_seed(0)
+    model = IDRNetwork(idr_conf(CFG)).cpu()
+    ref = R.RefIDR(model)
+    ref.train()
+    del model
+    inp, gt = synthetic_batch(1234, n_rays, "cpu")
+    loss_fn = IDRLoss(eikonal_weight=0.1, mask_weight=100.0, alpha=50.0)
+    cores = torch.get_num_threads()
+
+    def one():
+        out = ref(inp)
+        lo = loss_fn(out, gt)
+        ref.zero_grad()
+        lo["loss"].backward()
+
+    one()
     t0 = time.perf_counter()
-    reps = 0
-    while time.perf_counter() - t0 < 5.0:
-        O.encode_fwd(grid, x, table, B, 0)
-        reps += 1
+    for _ in range(reps):
+        one()
     dt = (time.perf_counter() - t0) / reps
-    return {"points_per_s": n / dt, "gbs": n * gather_bytes_per_point(L, 2) / dt / 1e9,
-            "cores": O.lib().hmo_num_threads(), "sample_points": n}
+    return {"value": round(n_rays / dt, 2), "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": f"{n_rays} of {RAYS_PER_GPU} rays, {reps} fwd+loss+bwd steps of oracle/torch_ref.py (torch-CPU, "
+                      f"{cores} threads), {dt:.2f} s/step"}
 
 
 def main():
@@ -104,17 +193,71 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--gather-only", action="store_true", help="only the hash-gather roofline section")
+    ap.add_argument("--rays", type=int, default=RAYS_PER_GPU, help="rays per GPU")
+    ap.add_argument("--no-extras", action="store_true", help="skip roofline / cpu_baseline sections")
     ap.add_argument("--gather-log2n", type=int, default=22)
-    ap.add_argument("--gather-cfg", default="C2")
     args = ap.parse_args()
 
-    if args.gather_only:
-        r = gather_roofline(args.gather_cfg, args.gather_log2n)
-        c = cpu_baseline_gather(args.gather_cfg)
-        print(json.dumps({"roofline": r, "cpu_gather": c}))
-        return
-    raise SystemExit("full ray step not wired yet")
+    from hashmodnffbanks_idr_amd import parallel
+    from hashmodnffbanks_idr_amd.model.implicit_differentiable_renderer import IDRNetwork
+    from hashmodnffbanks_idr_amd.model.loss import IDRLoss
+
+    rank, world, local_rank = parallel.init_distributed()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    torch.manual_seed(0)  # identical replicas on every rank
+    model = IDRNetwork(idr_conf(CFG)).to(device)
+    model.train()
+    loss_fn = IDRLoss(eikonal_weight=0.1, mask_weight=100.0, alpha=50.0)
+    opt = torch.optim.Adam(model.parameters(), lr=1.0e-4)
+    reducer = parallel.GradAllReducer(model.parameters()) if world > 1 else None
+    inp, gt = synthetic_batch(1234 + rank, args.rays, device)
+    torch.manual_seed(100 + rank)  # per-rank eikonal points / step fractions
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        parallel.train_step(model, loss_fn, opt, inp, gt, reducer)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        _, lo = parallel.train_step(model, loss_fn, opt, inp, gt, reducer)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        total_rays = args.rays * world * args.steps
+        line = {
+            "metric": "rays/sec fwd+bwd (hash+SDF MLP)", "value": round(total_rays / dt, 1), "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "DTU-shaped synthetic uniform-sphere rays, MultiResHash L=16 T=2^19 F=2 "
+                                   "(BASELINE.json configs[1]), full IDR training step",
+                       "rays_per_gpu": args.rays, "global_rays": args.rays * world,
+                       "parallelism": f"ray-sharded dp{world}" if world > 1 else "single GPU",
+                       "sdf_evals_per_ray_tracing": model.ray_tracer.last_stats},
+            "final_loss": round(float(lo["loss"].item()), 6),
+        }
+        if not args.no_extras:
+            emb = model.implicit_network.embed_model.embedder_obj
+            line["roofline"] = gather_roofline(emb, args.gather_log2n)
+            line["roofline_mlp"] = mlp_roofline(model.implicit_network)
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
