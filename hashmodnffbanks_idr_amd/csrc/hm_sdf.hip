@@ -77,8 +77,9 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_kernel(HmLevels lv, Sd
                                                                   const float *__restrict__ table,
                                                                   const float *__restrict__ Bf,
                                                                   float *__restrict__ out, int64_t out_stride,
-                                                                  int out_cols) {
+                                                                  int out_cols, const int32_t *__restrict__ n_dev) {
     extern __shared__ __align__(16) float lds[];
+    if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));  // device-side point count (sync-free callers)
     float *X = lds;
     float *EMB = lds + (size_t)net.x_groups * kGroupFloats;
     float *SX = EMB + (size_t)net.emb_groups * kGroupFloats;  // [64][3] raw points
@@ -272,6 +273,195 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_kernel(HmLevels lv, Sd
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// 16-point tile variant for SMALL batches (sphere-tracing rounds evaluate only 2 points per ray):
+// with 64-point tiles a 4096-point call occupies 64 of the 256 CUs for a full 9-layer latency.
+// Here a workgroup owns 16 points (v_mfma_f32_16x16x4_f32, 4 feature tiles of 16 per wave), so
+// the same call spreads over 256 workgroups; the price is 4x the weight traffic per point, which
+// L2 absorbs at this size.  Same LDS image X[k/4][point][4] (64 floats per k-group), same epilogue
+// identity: lane (point j, quarter q) holds features 4q..4q+3 of a tile = one k-group.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kPts16 = 16;
+constexpr int kGroupFloats16 = kPts16 * 4;
+
+template <int FRAC>
+__global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_m16_kernel(HmLevels lv, SdfNet net,
+                                                                      const float *__restrict__ x, int64_t n,
+                                                                      const float *__restrict__ table,
+                                                                      const float *__restrict__ Bf,
+                                                                      float *__restrict__ out, int64_t out_stride,
+                                                                      int out_cols, const int32_t *__restrict__ n_dev) {
+    extern __shared__ __align__(16) float lds[];
+    if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));
+    const int emb_groups16 = ((lv.E + 15) / 16) * 4;
+    float *X = lds;
+    float *EMB = lds + (size_t)net.x_groups * kGroupFloats16;
+    float *SX = EMB + (size_t)emb_groups16 * kGroupFloats16;  // [16][3]
+    float *RED = SX + kPts16 * 4;                              // [8][16]
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    const int j = lane & 15;  // point
+    const int q = lane >> 4;  // k quarter / feature quarter
+    const int L = lv.L, F = lv.F, E = lv.E;
+    const int64_t n_tiles = (n + kPts16 - 1) / kPts16;
+
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t base = tile * kPts16;
+        const int cnt = (int)min((int64_t)kPts16, n - base);
+        __syncthreads();
+        if (tid < kPts16 * 3) SX[tid] = (tid < cnt * 3) ? x[base * 3 + tid] : 0.0f;
+        __syncthreads();
+
+        // ---- encode: thread -> (point p, slot c); 32 slots cover channels / levels
+        {
+            const int p = tid & (kPts16 - 1);
+            const int c0 = tid >> 4;  // 0..31
+            const float x0 = SX[p * 3], x1 = SX[p * 3 + 1], x2 = SX[p * 3 + 2];
+            auto put = [&](int e, float v) { EMB[(e >> 2) * kGroupFloats16 + p * 4 + (e & 3)] = v; };
+            if (c0 == 0) {
+                put(0, x0); put(1, x1); put(2, x2);
+                for (int e = E; e < emb_groups16 * 4; ++e) put(e, 0.0f);
+            }
+            const float two_pi = 6.283185307179586f;
+            const float s0 = __fmul_rn(two_pi, x0), s1 = __fmul_rn(two_pi, x1), s2 = __fmul_rn(two_pi, x2);
+            for (int c = c0; c < L; c += 32) {
+                float a = __fmul_rn(s0, Bf[c]);
+                a = __fmaf_rn(s1, Bf[L + c], a);
+                a = __fmaf_rn(s2, Bf[2 * L + c], a);
+                float sn, cs;
+                sincosf(a, &sn, &cs);
+                put(3 + c, sn);
+                put(3 + L + c, cs);
+            }
+            for (int l = c0; l < L; l += 32) {
+                float acc[8];
+                for (int f = 0; f < F; ++f) acc[f] = 0.0f;
+                const float *tl = table + (size_t)lv.row_off[l] * F;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    uint32_t ux, uy, uz;
+                    float wx, wy, wz;
+                    corner<FRAC>(x0, lv.res[l], c & 1, ux, wx);
+                    corner<FRAC>(x1, lv.res[l], (c >> 1) & 1, uy, wy);
+                    corner<FRAC>(x2, lv.res[l], (c >> 2) & 1, uz, wz);
+                    const float w = __fmul_rn(__fmul_rn(wx, wy), wz);
+                    if (w != 0.0f) {
+                        const uint32_t id = hm_mod_rows(hm_hash3(ux, uy, uz), lv.rows[l], lv.magic[l]);
+                        for (int f = 0; f < F; ++f) acc[f] = __fadd_rn(acc[f], __fmul_rn(tl[(size_t)id * F + f], w));
+                    }
+                }
+                for (int f = 0; f < F; ++f) put(3 + 2 * L + l * F + f, acc[f]);
+            }
+        }
+        __syncthreads();
+
+        for (int li = 0; li < net.n_layers; ++li) {
+            const hm_mlp_layer &Ly = net.layer[li];
+            const int nb = Ly.seg_blocks16[0] + Ly.seg_blocks16[1];  // 16-wide k blocks
+            if (li == net.n_layers - 1 && out_cols == 1) {
+                // sdf-only last layer: VALU dot product, lane (point j, quarter q) walks k-groups == q (mod 4)
+                const float4 *W0 = reinterpret_cast<const float4 *>(Ly.w_packed_m16);
+                float part = 0.0f;
+                int t0 = 0;
+                for (int seg = 0; seg < 2; ++seg) {
+                    const float *src = (Ly.seg_src[seg] == 0) ? X : EMB;
+                    const int nbs = Ly.seg_blocks16[seg];
+                    for (int t = wave; t < nbs; t += kWaves) {
+                        const float4 xv = *reinterpret_cast<const float4 *>(src + (4 * t + q) * kGroupFloats16 + j * 4);
+                        const float4 wv = W0[(size_t)(t0 + t) * 64 + q * 16];
+                        part = __fmaf_rn(xv.x, wv.x, part);
+                        part = __fmaf_rn(xv.y, wv.y, part);
+                        part = __fmaf_rn(xv.z, wv.z, part);
+                        part = __fmaf_rn(xv.w, wv.w, part);
+                    }
+                    t0 += nbs;
+                }
+                part += __shfl_xor(part, 16);
+                part += __shfl_xor(part, 32);
+                if (q == 0) RED[wave * kPts16 + j] = part;
+                __syncthreads();
+                if (tid < cnt) {
+                    float sacc = Ly.bias[0];
+                    for (int w8 = 0; w8 < kWaves; ++w8) sacc += RED[w8 * kPts16 + tid];
+                    out[(base + tid) * out_stride] = sdf_clamp(sacc, net.beta);
+                }
+                break;
+            }
+            const int nt16 = Ly.n_tiles * 2;
+            const int u0 = 4 * wave;
+            const int ntw = max(0, min(4, nt16 - u0));
+            f32x4 acc[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[a] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (ntw > 0) {
+                const float4 *A = reinterpret_cast<const float4 *>(Ly.w_packed_m16) + ((size_t)u0 * nb) * 64 + lane;
+                const size_t tstride = (size_t)nb * 64;  // next feature tile
+                float4 av[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) av[a] = A[(a < ntw ? a : 0) * tstride];
+                int tt = 0;
+                for (int seg = 0; seg < 2; ++seg) {
+                    const float *src = (Ly.seg_src[seg] == 0) ? X : EMB;
+                    const int nbs = Ly.seg_blocks16[seg];
+                    for (int t = 0; t < nbs; ++t, ++tt) {
+                        const float4 b = *reinterpret_cast<const float4 *>(src + (4 * t + q) * kGroupFloats16 + j * 4);
+                        const int nxt = (tt + 1 < nb) ? tt + 1 : tt;
+                        float4 an[4];
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) an[a] = A[(a < ntw ? a : 0) * tstride + (size_t)nxt * 64];
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) {
+                            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a].x, b.x, acc[a], 0, 0, 0);
+                            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a].y, b.y, acc[a], 0, 0, 0);
+                            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a].z, b.z, acc[a], 0, 0, 0);
+                            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a].w, b.w, acc[a], 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) av[a] = an[a];
+                    }
+                }
+            }
+            __syncthreads();
+            const bool act = Ly.activation != 0;
+            const bool div = Ly.post_div_sqrt2 != 0;
+            const float sqrt2 = 1.41421356237309515f;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                if (a >= ntw) continue;
+                const int f = 16 * (u0 + a) + 4 * q;
+                const float4 bb = *reinterpret_cast<const float4 *>(Ly.bias + f);
+                float v0 = acc[a][0] + bb.x, v1 = acc[a][1] + bb.y, v2 = acc[a][2] + bb.z, v3 = acc[a][3] + bb.w;
+                if (act) {
+                    v0 = softplus100(v0); v1 = softplus100(v1); v2 = softplus100(v2); v3 = softplus100(v3);
+                }
+                if (div) {
+                    v0 = __fdiv_rn(v0, sqrt2); v1 = __fdiv_rn(v1, sqrt2); v2 = __fdiv_rn(v2, sqrt2);
+                    v3 = __fdiv_rn(v3, sqrt2);
+                }
+                *reinterpret_cast<float4 *>(X + (f >> 2) * kGroupFloats16 + j * 4) = make_float4(v0, v1, v2, v3);
+            }
+            if (li == 0) {
+                for (int i = tid; i < emb_groups16 * kGroupFloats16; i += kThreadsSdf) EMB[i] = __fdiv_rn(EMB[i], sqrt2);
+            }
+            __syncthreads();
+        }
+
+        const hm_mlp_layer &last = net.layer[net.n_layers - 1];
+        if (out_cols != 1) {
+            const int od = last.out_dim;
+            for (int i = tid; i < cnt * od; i += kThreadsSdf) {
+                const int p = i / od, f = i - p * od;
+                float v = X[(f >> 2) * kGroupFloats16 + p * 4 + (f & 3)];
+                if (f == 0) v = sdf_clamp(v, net.beta);
+                out[(base + p) * out_stride + f] = v;
+            }
+        }
+    }
+}
+
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 }  // namespace
@@ -279,35 +469,44 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 extern "C" {
 
 int hm_sdf_fwd(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *x, int64_t n, const float *table,
-               const float *B_fourier, float *out, int64_t out_stride, int out_cols, int frac_mode,
-               int max_workgroups, void *stream) {
+               const float *B_fourier, float *out, int64_t out_stride, int out_cols, int frac_mode, int tile_points,
+               const int32_t *n_dev, int max_workgroups, void *stream) {
     HM_CHECK_ARG(desc && mlp, "hm_sdf_fwd: NULL descriptor");
     HM_CHECK_ARG(n >= 0, "hm_sdf_fwd: n < 0");
     HM_CHECK_ARG(frac_mode == HM_FRAC_REFERENCE || frac_mode == HM_FRAC_TRILINEAR, "hm_sdf_fwd: bad frac_mode");
     HM_CHECK_ARG(mlp->n_layers >= 1 && mlp->n_layers <= HM_MAX_LAYERS, "hm_sdf_fwd: n_layers out of range");
+    HM_CHECK_ARG(tile_points == 0 || tile_points == 16 || tile_points == 64, "hm_sdf_fwd: tile_points must be 0, 16 or 64");
     const HmLevels &lv = desc->lv;
     SdfNet net;
     net.n_layers = mlp->n_layers;
     net.beta = mlp->beta;
     const int emb_oct = (lv.E + 7) / 8;
+    const int emb_b16 = (lv.E + 15) / 16;
     net.emb_groups = emb_oct * 2;
     int x_groups = 0;
+    bool have16 = true;
     for (int l = 0; l < mlp->n_layers; ++l) {
         const hm_mlp_layer &Ly = mlp->layer[l];
         HM_CHECK_ARG(Ly.w_packed && Ly.bias, "hm_sdf_fwd: layer has NULL weights/bias");
         HM_CHECK_ARG(Ly.n_tiles >= 1 && Ly.n_tiles <= 2 * kWaves, "hm_sdf_fwd: layer wider than 512 features");
         HM_CHECK_ARG(Ly.out_dim >= 1 && Ly.out_dim <= Ly.n_tiles * 32, "hm_sdf_fwd: out_dim / n_tiles mismatch");
         HM_CHECK_ARG(Ly.seg_octets[0] >= 1 && Ly.seg_octets[1] >= 0, "hm_sdf_fwd: bad segment length");
+        if (!Ly.w_packed_m16) have16 = false;
         for (int s = 0; s < 2; ++s) {
             if (Ly.seg_octets[s] == 0) continue;
             if (Ly.seg_src[s] == 1) {
                 HM_CHECK_ARG(Ly.seg_octets[s] == emb_oct, "hm_sdf_fwd: embedding segment must span ceil(E/8) octets");
+                HM_CHECK_ARG(!Ly.w_packed_m16 || Ly.seg_blocks16[s] == emb_b16,
+                             "hm_sdf_fwd: embedding segment must span ceil(E/16) 16-blocks");
             } else {
                 HM_CHECK_ARG(Ly.seg_src[s] == 0 && l > 0, "hm_sdf_fwd: layer 0 must read the embedding");
                 HM_CHECK_ARG(Ly.seg_octets[s] * 8 <= mlp->layer[l - 1].n_tiles * 32,
                              "hm_sdf_fwd: layer reads more inputs than the previous layer produces");
                 HM_CHECK_ARG(Ly.seg_octets[s] * 8 >= mlp->layer[l - 1].out_dim,
                              "hm_sdf_fwd: layer reads fewer inputs than the previous layer produces");
+                HM_CHECK_ARG(!Ly.w_packed_m16 || (Ly.seg_blocks16[s] * 16 <= mlp->layer[l - 1].n_tiles * 32 &&
+                                                  Ly.seg_blocks16[s] * 16 >= mlp->layer[l - 1].out_dim),
+                             "hm_sdf_fwd: 16-block segment length does not match the previous layer");
             }
         }
         x_groups = max(x_groups, Ly.n_tiles * 8);
@@ -317,14 +516,11 @@ int hm_sdf_fwd(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *x,
     const hm_mlp_layer &last = mlp->layer[mlp->n_layers - 1];
     HM_CHECK_ARG(out_cols == 1 || out_cols == last.out_dim, "hm_sdf_fwd: out_cols must be 1 or the last layer's out_dim");
     HM_CHECK_ARG(out_stride >= out_cols, "hm_sdf_fwd: out_stride < out_cols");
+    HM_CHECK_ARG(tile_points != 16 || have16, "hm_sdf_fwd: tile_points 16 needs w_packed_m16 in every layer");
     if (n == 0) return HM_OK;
     HM_CHECK_ARG(x && table && B_fourier && out, "hm_sdf_fwd: NULL pointer");
-    const size_t lds = sizeof(float) * ((size_t)(net.x_groups + net.emb_groups) * kGroupFloats + kPts * 4 + kWaves * kPts);
-    HM_CHECK_ARG(lds <= 160 * 1024, "hm_sdf_fwd: network does not fit the 160 KB LDS tile");
-    const int64_t tiles = (n + kPts - 1) / kPts;
-    int64_t grid = tiles;
-    const int64_t cap = max_workgroups > 0 ? max_workgroups : 256;
-    if (grid > cap) grid = cap;
+    // small batches: 16-point tiles spread the call over the whole chip (see sdf_fwd_m16_kernel)
+    const bool use16 = have16 && (tile_points == 16 || (tile_points == 0 && n <= 8192));
     static thread_local bool attr_done = false;
     if (!attr_done) {  // opt in to >64 KB dynamic LDS once (not a stream operation)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sdf_fwd_kernel<HM_FRAC_REFERENCE>),
@@ -335,12 +531,32 @@ int hm_sdf_fwd(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *x,
         if (e != hipSuccess) return hm_fail(HM_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
         attr_done = true;
     }
-    if (frac_mode == HM_FRAC_REFERENCE) {
-        hipLaunchKernelGGL(sdf_fwd_kernel<HM_FRAC_REFERENCE>, dim3((unsigned)grid), dim3(kThreadsSdf), lds,
-                           as_stream(stream), lv, net, x, n, table, B_fourier, out, out_stride, out_cols);
+    if (use16) {
+        const size_t lds = sizeof(float) * ((size_t)(net.x_groups + emb_b16 * 4) * kGroupFloats16 + kPts16 * 4 +
+                                            kWaves * kPts16);
+        HM_CHECK_ARG(lds <= 64 * 1024, "hm_sdf_fwd: network does not fit the 16-point LDS tile");
+        const int64_t tiles = (n + kPts16 - 1) / kPts16;
+        const int64_t cap = max_workgroups > 0 ? max_workgroups : 512;
+        const int64_t grid = tiles < cap ? tiles : cap;
+        if (frac_mode == HM_FRAC_REFERENCE)
+            hipLaunchKernelGGL(sdf_fwd_m16_kernel<HM_FRAC_REFERENCE>, dim3((unsigned)grid), dim3(kThreadsSdf), lds,
+                               as_stream(stream), lv, net, x, n, table, B_fourier, out, out_stride, out_cols, n_dev);
+        else
+            hipLaunchKernelGGL(sdf_fwd_m16_kernel<HM_FRAC_TRILINEAR>, dim3((unsigned)grid), dim3(kThreadsSdf), lds,
+                               as_stream(stream), lv, net, x, n, table, B_fourier, out, out_stride, out_cols, n_dev);
     } else {
-        hipLaunchKernelGGL(sdf_fwd_kernel<HM_FRAC_TRILINEAR>, dim3((unsigned)grid), dim3(kThreadsSdf), lds,
-                           as_stream(stream), lv, net, x, n, table, B_fourier, out, out_stride, out_cols);
+        const size_t lds = sizeof(float) * ((size_t)(net.x_groups + net.emb_groups) * kGroupFloats + kPts * 4 +
+                                            kWaves * kPts);
+        HM_CHECK_ARG(lds <= 160 * 1024, "hm_sdf_fwd: network does not fit the 160 KB LDS tile");
+        const int64_t tiles = (n + kPts - 1) / kPts;
+        const int64_t cap = max_workgroups > 0 ? max_workgroups : 256;
+        const int64_t grid = tiles < cap ? tiles : cap;
+        if (frac_mode == HM_FRAC_REFERENCE)
+            hipLaunchKernelGGL(sdf_fwd_kernel<HM_FRAC_REFERENCE>, dim3((unsigned)grid), dim3(kThreadsSdf), lds,
+                               as_stream(stream), lv, net, x, n, table, B_fourier, out, out_stride, out_cols, n_dev);
+        else
+            hipLaunchKernelGGL(sdf_fwd_kernel<HM_FRAC_TRILINEAR>, dim3((unsigned)grid), dim3(kThreadsSdf), lds,
+                               as_stream(stream), lv, net, x, n, table, B_fourier, out, out_stride, out_cols, n_dev);
     }
     HM_CHECK_LAUNCH("hm_sdf_fwd");
     return HM_OK;

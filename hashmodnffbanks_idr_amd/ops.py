@@ -224,28 +224,33 @@ def linear(x, weight, bias=None):
 # =========================================================================================
 # fused no-grad SDF forward (csrc/hm_sdf.hip)
 # =========================================================================================
-def pack_mlp_layer(W, segs):
+def pack_mlp_layer(W, segs, kblock=8):
     """Packed MFMA operand image of one folded layer (layout contract: include/hashmod.h).
 
     W [out, sum(real segment widths)];  segs = [(src, real_width), ...] with src 1 = embedding,
-    0 = previous layer output.  Returns (w_packed, n_tiles, seg_octets, seg_src)."""
+    0 = previous layer output.  kblock 8: image for the 64-point kernel (32-row tiles, octets);
+    kblock 16: image for the 16-point kernel (16-row tiles, 16-wide k blocks).
+    Returns (w_packed, n_tiles, seg_blocks, seg_src)."""
     out_dim = W.shape[0]
     n_tiles = (out_dim + 31) // 32
     cols, c0, octs, srcs = [], 0, [], []
     for src, width in segs:
-        pad = (-width) % 8
+        pad = (-width) % kblock
         blk = W[:, c0:c0 + width]
         if pad:
             blk = torch.nn.functional.pad(blk, (0, pad))
         cols.append(blk)
-        octs.append((width + pad) // 8)
+        octs.append((width + pad) // kblock)
         srcs.append(src)
         c0 += width
     assert c0 == W.shape[1]
     Wp = torch.cat(cols, 1)
     Wp = torch.nn.functional.pad(Wp, (0, 0, 0, n_tiles * 32 - out_dim))
-    G = Wp.shape[1] // 8
-    Wp = Wp.view(n_tiles, 32, G, 2, 4).permute(0, 2, 3, 1, 4).contiguous()
+    G = Wp.shape[1] // kblock
+    if kblock == 8:   # [u][g][h][i][s]  <- W[32u+i][8g+4h+s]
+        Wp = Wp.view(n_tiles, 32, G, 2, 4).permute(0, 2, 3, 1, 4).contiguous()
+    else:             # [u][t][q][i][e]  <- W[16u+i][16t+4q+e]
+        Wp = Wp.view(n_tiles * 2, 16, G, 4, 4).permute(0, 2, 3, 1, 4).contiguous()
     while len(octs) < 2:
         octs.append(0)
         srcs.append(0)
@@ -271,10 +276,13 @@ class PackedSdf:
             else:
                 segs = [(0, prev_out)]
             Wp, n_tiles, octs, srcs = pack_mlp_layer(W, segs)
+            Wq, _, blk16, _ = pack_mlp_layer(W, segs, kblock=16)
             b = torch.nn.functional.pad(biases[l].detach().float(), (0, n_tiles * 32 - W.shape[0])).contiguous()
-            self.keep += [Wp, b]
+            self.keep += [Wp, Wq, b]
             ly = self.desc.layer[l]
             ly.w_packed, ly.bias = Wp.data_ptr(), b.data_ptr()
+            ly.w_packed_m16 = Wq.data_ptr()
+            ly.seg_blocks16[0], ly.seg_blocks16[1] = blk16[0], blk16[1]
             ly.out_dim, ly.n_tiles = W.shape[0], n_tiles
             ly.seg_octets[0], ly.seg_octets[1] = octs[0], octs[1]
             ly.seg_src[0], ly.seg_src[1] = srcs[0], srcs[1]
@@ -284,13 +292,16 @@ class PackedSdf:
         self.out_dim = prev_out
 
 
-def sdf_fwd(desc, packed, x, table, B, frac_mode=0, sdf_only=False, max_workgroups=0):
-    """Fused encode + MLP + clamp.  Returns [N] (sdf_only) or [N, out_dim]."""
+def sdf_fwd(desc, packed, x, table, B, frac_mode=0, sdf_only=False, max_workgroups=0, tile_points=0, n_dev=None):
+    """Fused encode + MLP + clamp.  Returns [N] (sdf_only) or [N, out_dim].
+    tile_points 0 = auto (16-point tiles for small batches, 64 otherwise); n_dev = optional device
+    int32 tensor holding the live point count (the call is then sync-free for device-compacted work)."""
     x = _prep_x(x)
     require_gpu(x, table, B)
     n = x.shape[0]
     cols = 1 if sdf_only else packed.out_dim
     out = torch.empty((n, cols), dtype=torch.float32, device=x.device)
     check(lib().hm_sdf_fwd(desc.handle, C.byref(packed.desc), dptr(x), n, dptr(table), dptr(B.contiguous()),
-                           dptr(out), cols, cols, int(frac_mode), int(max_workgroups), stream_ptr(x)))
+                           dptr(out), cols, cols, int(frac_mode), int(tile_points), dptr(n_dev),
+                           int(max_workgroups), stream_ptr(x)))
     return out[:, 0] if sdf_only else out

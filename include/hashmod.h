@@ -115,6 +115,11 @@ typedef struct hm_mlp_layer {
     int32_t seg_src[2];     /* 0 previous layer output, 1 embedding      */
     int32_t activation;     /* 1: Softplus(beta=100, threshold=20), 0: none */
     int32_t post_div_sqrt2; /* 1: outputs are divided by sqrt(2) (feeds the skip concat) */
+    /* optional second image for the 16-point-tile kernel (small batches); NULL = not provided.
+     * Same K space but every segment zero-padded to a multiple of 16; nb = seg_blocks16[0]+[1];
+     * w_packed_m16[((u*nb + t)*64 + l)*4 + e] = W[16u + (l&15)][16t + 4(l>>4) + e],  u < 2*n_tiles. */
+    const float *w_packed_m16;
+    int32_t seg_blocks16[2];
 } hm_mlp_layer;
 
 typedef struct hm_mlp_desc {
@@ -124,10 +129,14 @@ typedef struct hm_mlp_desc {
 } hm_mlp_desc;
 
 /* x [n,3] -> out.  out_cols == 1: only the clamped sdf, out[i*out_stride];  out_cols == last
- * layer's out_dim: the whole [sdf | feature vector] row.  max_workgroups <= 0: one per CU (256). */
+ * layer's out_dim: the whole [sdf | feature vector] row.
+ * tile_points: 64 (one workgroup per CU, throughput), 16 (small batches), 0 = choose by n.
+ * n_dev: optional DEVICE int32; when non-NULL the kernel evaluates min(n, *n_dev) points, so a
+ *        caller that compacts work on the device needs no host synchronisation (n is the capacity).
+ * max_workgroups <= 0: fill the chip once (persistent grid-stride over tiles).                    */
 HM_API int hm_sdf_fwd(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *x, int64_t n,
                       const float *table, const float *B_fourier, float *out, int64_t out_stride, int out_cols,
-                      int frac_mode, int max_workgroups, void *stream);
+                      int frac_mode, int tile_points, const int32_t *n_dev, int max_workgroups, void *stream);
 
 /* ---- exact-fp32 GEMM (grad-enabled MLP path) ------------------------------------------------
  * Replaces the nn.Linear matmuls autograd runs for the SDF and rendering MLPs when gradients are
