@@ -90,6 +90,7 @@ class ImplicitNetwork(nn.Module):
             p.requires_grad = True
         self._packed = None
         self._packed_key = None
+        self.sdf_tile_points = 0  # fused kernel tile: 0 auto (16-point tiles for small batches), 16, 64
 
     # ---- fused no-grad path ---------------------------------------------------------------
     def _hash_embedder(self):
@@ -127,7 +128,7 @@ class ImplicitNetwork(nn.Module):
     def _fused(self, x, sdf_only):
         emb = self._hash_embedder()
         return ops.sdf_fwd(emb.desc, self.packed_weights(), x, emb.table.detach(), emb.freq_encoding.B,
-                           ops.FRAC_MODES[emb.frac_mode], sdf_only=sdf_only)
+                           ops.FRAC_MODES[emb.frac_mode], sdf_only=sdf_only, tile_points=self.sdf_tile_points)
 
     def sdf(self, x):
         """no-grad SDF values [N] - the callable handed to RayTracing (reference passes

@@ -22,10 +22,12 @@ def _close(a, b, rtol=1e-5, atol=2e-6, what=""):
     np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, err_msg=what)
 
 
+@pytest.mark.parametrize("tile", [16, 64])
 @pytest.mark.parametrize("tag,cfg", CASES)
-def test_fused_forward_golden(golden, tag, cfg):
+def test_fused_forward_golden(golden, tag, cfg, tile):
     g = golden(f"sdf_{tag}")
     net = _net(g, cfg)
+    net.sdf_tile_points = tile
     x = torch.from_numpy(g["x"]).cuda()
     with torch.no_grad():
         out = net(x)
@@ -34,10 +36,12 @@ def test_fused_forward_golden(golden, tag, cfg):
     _close(sdf.cpu().numpy(), g["out"][:, 0], what="fused sdf-only output")
 
 
-@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 64 * 300 + 5])
-def test_fused_forward_vs_oracle_ragged(golden, n):
+@pytest.mark.parametrize("tile", [0, 16, 64])
+@pytest.mark.parametrize("n", [1, 15, 17, 63, 64, 65, 1000, 64 * 300 + 5])
+def test_fused_forward_vs_oracle_ragged(golden, n, tile):
     g = golden("sdf_full")
     net = _net(g, "C1")
+    net.sdf_tile_points = tile
     L, T, b, d = P.CONFIGS["C1"]
     seed = int(g["seed"])
     levels, B, _, _ = P.make_embedder_state(seed, "C1", float(g["table_scale"]))
@@ -150,3 +154,18 @@ def test_matmul_double_backward_vs_torch():
     ref = run(torch.nn.functional.linear)
     for a_, b_ in zip(got, ref):
         np.testing.assert_allclose(a_.cpu().numpy(), b_.cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_fused_device_side_count():
+    """n_dev: the kernel evaluates min(n, *n_dev) points without a host round trip."""
+    from hashmodnffbanks_idr_amd import ops
+    net = make_implicit("tiny", (64,) * 8, 16, 3, 0.5, 0.5)
+    emb = net.embed_model.embedder_obj
+    x = torch.from_numpy(P.make_points(2, 500)).cuda()
+    full = net.sdf(x)
+    for tile in (16, 64):
+        n_dev = torch.tensor([137], dtype=torch.int32, device="cuda")
+        pk = net.packed_weights()
+        res = ops.sdf_fwd(emb.desc, pk, x, emb.table.detach(), emb.freq_encoding.B, 0, sdf_only=True,
+                          tile_points=tile, n_dev=n_dev)
+        assert torch.allclose(res[:137], full[:137], rtol=1e-6, atol=1e-7)
