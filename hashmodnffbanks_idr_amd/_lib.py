@@ -28,6 +28,9 @@ SIGNATURES = {
     "hm_encode_fwd": (_int, [_p, _p, _i64, _p, _p, _p, _i64, _int, _p]),
     "hm_encode_bwd_table": (_int, [_p, _p, _i64, _p, _i64, _p, _int, _p]),
     "hm_sdf_fwd": (_int, [_p, _p, _p, _i64, _p, _p, _p, _i64, _int, _int, _int, _p, _int, _p]),
+    "hm_trace_workspace_bytes": (_i64, [_i64, _p]),
+    "hm_trace_forward": (_int, [_p, _p, _p, _p, _int, _int, _p, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _p, _p, _p,
+                                _i64, _p, _p]),
     "hm_gemm_f32": (_int, [_int, _int, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _int, _p]),
 }
 
@@ -36,6 +39,12 @@ class MlpLayer(C.Structure):
     _fields_ = [("w_packed", C.c_void_p), ("bias", C.c_void_p), ("out_dim", C.c_int32), ("n_tiles", C.c_int32),
                 ("seg_octets", C.c_int32 * 2), ("seg_src", C.c_int32 * 2), ("activation", C.c_int32),
                 ("post_div_sqrt2", C.c_int32), ("w_packed_m16", C.c_void_p), ("seg_blocks16", C.c_int32 * 2)]
+
+
+class TraceCfg(C.Structure):
+    _fields_ = [("object_bounding_sphere", C.c_float), ("sdf_threshold", C.c_float), ("line_search_step", C.c_double),
+                ("line_step_iters", C.c_int32), ("sphere_tracing_iters", C.c_int32), ("n_steps", C.c_int32),
+                ("n_secant_steps", C.c_int32), ("training", C.c_int32)]
 
 
 class MlpDesc(C.Structure):

@@ -77,9 +77,11 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_kernel(HmLevels lv, Sd
                                                                   const float *__restrict__ table,
                                                                   const float *__restrict__ Bf,
                                                                   float *__restrict__ out, int64_t out_stride,
-                                                                  int out_cols, const int32_t *__restrict__ n_dev) {
+                                                                  int out_cols, const int32_t *__restrict__ n_dev, int64_t run_min,
+                                                                  int64_t run_max) {
     extern __shared__ __align__(16) float lds[];
     if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));  // device-side point count (sync-free callers)
+    if (n < run_min || n > run_max) return;          // the other tile-size kernel owns this batch size
     float *X = lds;
     float *EMB = lds + (size_t)net.x_groups * kGroupFloats;
     float *SX = EMB + (size_t)net.emb_groups * kGroupFloats;  // [64][3] raw points
@@ -291,9 +293,11 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_m16_kernel(HmLevels lv
                                                                       const float *__restrict__ table,
                                                                       const float *__restrict__ Bf,
                                                                       float *__restrict__ out, int64_t out_stride,
-                                                                      int out_cols, const int32_t *__restrict__ n_dev) {
+                                                                      int out_cols, const int32_t *__restrict__ n_dev, int64_t run_min,
+                                                                      int64_t run_max) {
     extern __shared__ __align__(16) float lds[];
     if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));
+    if (n < run_min || n > run_max) return;
     const int emb_groups16 = ((lv.E + 15) / 16) * 4;
     float *X = lds;
     float *EMB = lds + (size_t)net.x_groups * kGroupFloats16;
@@ -519,8 +523,18 @@ int hm_sdf_fwd(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *x,
     HM_CHECK_ARG(tile_points != 16 || have16, "hm_sdf_fwd: tile_points 16 needs w_packed_m16 in every layer");
     if (n == 0) return HM_OK;
     HM_CHECK_ARG(x && table && B_fourier && out, "hm_sdf_fwd: NULL pointer");
-    // small batches: 16-point tiles spread the call over the whole chip (see sdf_fwd_m16_kernel)
-    const bool use16 = have16 && (tile_points == 16 || (tile_points == 0 && n <= 8192));
+    // small batches: 16-point tiles spread the call over the whole chip (see sdf_fwd_m16_kernel).
+    // With a device-side count the host cannot know the batch size: both kernels are enqueued and
+    // each returns at once unless the live count falls in its range.
+    constexpr int64_t kSmall = 8192;
+    const int64_t kBig = (int64_t)1 << 62;
+    bool run16 = false, run64 = false;
+    int64_t lo16 = 0, hi16 = kBig, lo64 = 0, hi64 = kBig;
+    if (tile_points == 16) run16 = true;
+    else if (tile_points == 64 || !have16) run64 = true;
+    else if (!n_dev) { run16 = n <= kSmall; run64 = !run16; }
+    else if (n <= kSmall) run16 = true;
+    else { run16 = run64 = true; hi16 = kSmall; lo64 = kSmall + 1; }
     static thread_local bool attr_done = false;
     if (!attr_done) {  // opt in to >64 KB dynamic LDS once (not a stream operation)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sdf_fwd_kernel<HM_FRAC_REFERENCE>),
@@ -531,20 +545,24 @@ int hm_sdf_fwd(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *x,
         if (e != hipSuccess) return hm_fail(HM_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
         attr_done = true;
     }
-    if (use16) {
+    if (run16) {
         const size_t lds = sizeof(float) * ((size_t)(net.x_groups + emb_b16 * 4) * kGroupFloats16 + kPts16 * 4 +
                                             kWaves * kPts16);
         HM_CHECK_ARG(lds <= 64 * 1024, "hm_sdf_fwd: network does not fit the 16-point LDS tile");
-        const int64_t tiles = (n + kPts16 - 1) / kPts16;
+        const int64_t nmax = n < hi16 ? n : hi16;
+        const int64_t tiles = (nmax + kPts16 - 1) / kPts16;
         const int64_t cap = max_workgroups > 0 ? max_workgroups : 512;
         const int64_t grid = tiles < cap ? tiles : cap;
         if (frac_mode == HM_FRAC_REFERENCE)
             hipLaunchKernelGGL(sdf_fwd_m16_kernel<HM_FRAC_REFERENCE>, dim3((unsigned)grid), dim3(kThreadsSdf), lds,
-                               as_stream(stream), lv, net, x, n, table, B_fourier, out, out_stride, out_cols, n_dev);
+                               as_stream(stream), lv, net, x, n, table, B_fourier, out, out_stride, out_cols, n_dev,
+                               lo16, hi16);
         else
             hipLaunchKernelGGL(sdf_fwd_m16_kernel<HM_FRAC_TRILINEAR>, dim3((unsigned)grid), dim3(kThreadsSdf), lds,
-                               as_stream(stream), lv, net, x, n, table, B_fourier, out, out_stride, out_cols, n_dev);
-    } else {
+                               as_stream(stream), lv, net, x, n, table, B_fourier, out, out_stride, out_cols, n_dev,
+                               lo16, hi16);
+    }
+    if (run64) {
         const size_t lds = sizeof(float) * ((size_t)(net.x_groups + net.emb_groups) * kGroupFloats + kPts * 4 +
                                             kWaves * kPts);
         HM_CHECK_ARG(lds <= 160 * 1024, "hm_sdf_fwd: network does not fit the 160 KB LDS tile");
@@ -553,10 +571,12 @@ int hm_sdf_fwd(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *x,
         const int64_t grid = tiles < cap ? tiles : cap;
         if (frac_mode == HM_FRAC_REFERENCE)
             hipLaunchKernelGGL(sdf_fwd_kernel<HM_FRAC_REFERENCE>, dim3((unsigned)grid), dim3(kThreadsSdf), lds,
-                               as_stream(stream), lv, net, x, n, table, B_fourier, out, out_stride, out_cols, n_dev);
+                               as_stream(stream), lv, net, x, n, table, B_fourier, out, out_stride, out_cols, n_dev,
+                               lo64, hi64);
         else
             hipLaunchKernelGGL(sdf_fwd_kernel<HM_FRAC_TRILINEAR>, dim3((unsigned)grid), dim3(kThreadsSdf), lds,
-                               as_stream(stream), lv, net, x, n, table, B_fourier, out, out_stride, out_cols, n_dev);
+                               as_stream(stream), lv, net, x, n, table, B_fourier, out, out_stride, out_cols, n_dev,
+                               lo64, hi64);
     }
     HM_CHECK_LAUNCH("hm_sdf_fwd");
     return HM_OK;

@@ -1,0 +1,488 @@
+// hm_trace.hip - sync-free ray/surface intersection search for gfx950: IDR's bidirectional
+// sphere tracing, sign-change sampler + secant refinement and the closest-approach search,
+// restated as PER-RAY STATE MACHINES driven by small update kernels around the fused SDF kernel.
+//
+// Replaces RayTracing.forward / sphere_tracing / ray_sampler / secant / minimal_sdf_points
+// (reference: model/ray_tracing.py:26-298).  Every update in the reference is gated by a per-ray
+// mask, so each ray can run its own state machine; the reference's
+// host-side control flow (>= 9 device->host syncs, boolean-mask gathers with data-dependent
+// shapes) disappears: each round is  [advance rays, append the points they need to a compact
+// buffer with an atomic cursor]  ->  [fused SDF kernel over min(capacity, *cursor) points, the
+// count read on the device].  One C call enqueues the whole search; nothing synchronises.
+//
+// Arithmetic is kept bit-compatible with the reference's elementwise fp32 expressions
+// (p = cam + t*dir as mul-then-add, t +/- sdf, the secant formula's evaluation order); the file
+// is compiled with -ffp-contract=off.
+#include "hm_common.h"
+
+namespace {
+
+constexpr int kTB = 256;
+
+enum : int32_t {  // counters (device int32 array)
+    C_ROUND0 = 0,        // [0..63] points appended in march round r
+    C_NSAMP = 64,        // rays handed to the sampler
+    C_NSAMP_PTS = 65,    // C_NSAMP * n_steps
+    C_NSEC = 66,         // rays in the secant refinement
+    C_NSEL = 67,         // mask-loss rays for the closest-approach search
+    C_NSEL_PTS = 68,
+    C_ANY_LIVE = 69,     // some ray was still marching after the first evaluation (=> >= 1 global iteration)
+    C_EVALS = 70,        // total SDF point evaluations (statistics)
+    C_UNFINISHED = 71,   // rays whose state machine had not finished after the last march round
+    C_COUNT = 80
+};
+
+enum : uint8_t { ST_WAIT_FIRST = 1, ST_WAIT_MARCH = 2, ST_WAIT_LS = 3, ST_DONE = 4 };
+
+struct TraceWs {
+    float *t_s, *t_e, *t_min, *t_max, *cur_s, *cur_e, *nxt_s, *nxt_e;  // [N]
+    float *z_lo, *z_hi, *v_lo, *v_hi, *z;                               // [N] secant state by secant slot
+    int32_t *slot_s, *slot_e, *list_samp, *list_sec, *list_sel;          // [N]
+    uint8_t *live_s, *live_e, *stage, *it, *k, *is_samp;                // [N]
+    float *pts;    // [cap,3]
+    float *vals;   // [cap]
+    int32_t *cnt;  // [C_COUNT]
+    int64_t cap;
+};
+
+struct TraceArgs {
+    TraceWs w;
+    const float *cam;        // [B,3]
+    const float *dirs;       // [N,3]
+    const uint8_t *obj;      // [N]
+    const float *t_sphere;   // [N,2]
+    const uint8_t *hit;      // [N]
+    const float *fracs;      // [n_steps] linspace(0,1)
+    const float *steps_u;    // [n_steps] shared random fractions (training tail)
+    float *out_pts;          // [N,3]
+    uint8_t *out_mask;       // [N]
+    float *out_t;            // [N]
+    int64_t n, rays_per_image;
+    float thr;
+    float back[4];           // (1 - line_search_step) / 2^k, formed in double on the host
+    int32_t ls_iters, max_it, n_steps, n_secant, training;
+};
+
+__device__ __forceinline__ void along(const TraceArgs &a, int64_t i, float t, float &px, float &py, float &pz) {
+    const float *c = a.cam + (i / a.rays_per_image) * 3;
+    const float *d = a.dirs + i * 3;
+    px = __fadd_rn(c[0], __fmul_rn(t, d[0]));
+    py = __fadd_rn(c[1], __fmul_rn(t, d[1]));
+    pz = __fadd_rn(c[2], __fmul_rn(t, d[2]));
+}
+
+__device__ __forceinline__ int32_t append_point(const TraceArgs &a, int32_t *cursor, int64_t i, float t) {
+    const int32_t idx = atomicAdd(cursor, 1);
+    float px, py, pz;
+    along(a, i, t, px, py, pz);
+    a.w.pts[(int64_t)idx * 3 + 0] = px;
+    a.w.pts[(int64_t)idx * 3 + 1] = py;
+    a.w.pts[(int64_t)idx * 3 + 2] = pz;
+    return idx;
+}
+
+// round 0: both sphere intersections of every ray that hits the bounding sphere (ray_tracing.py:101-128)
+__global__ __launch_bounds__(kTB) void trace_init_kernel(TraceArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * kTB + threadIdx.x;
+    if (i >= a.n) return;
+    const TraceWs &w = a.w;
+    const bool hit = a.hit[i] != 0;
+    const float ts = hit ? a.t_sphere[2 * i] : 0.0f, te = hit ? a.t_sphere[2 * i + 1] : 0.0f;
+    w.t_s[i] = ts; w.t_e[i] = te; w.t_min[i] = ts; w.t_max[i] = te;
+    w.cur_s[i] = 0.0f; w.cur_e[i] = 0.0f; w.nxt_s[i] = 0.0f; w.nxt_e[i] = 0.0f;
+    w.live_s[i] = hit; w.live_e[i] = hit;
+    w.it[i] = 0; w.k[i] = 0; w.is_samp[i] = 0;
+    w.stage[i] = ST_WAIT_FIRST;
+    w.slot_s[i] = hit ? append_point(a, w.cnt + C_ROUND0, i, ts) : -1;
+    w.slot_e[i] = hit ? append_point(a, w.cnt + C_ROUND0, i, te) : -1;
+}
+
+// one round of the per-ray sphere-tracing state machine (ray_tracing.py:130-186)
+__global__ __launch_bounds__(kTB) void trace_advance_kernel(TraceArgs a, int round) {
+    const int64_t i = (int64_t)blockIdx.x * kTB + threadIdx.x;
+    if (i >= a.n) return;
+    const TraceWs &w = a.w;
+    uint8_t st = w.stage[i];
+    if (st == ST_DONE) return;
+    float t_s = w.t_s[i], t_e = w.t_e[i], cur_s = w.cur_s[i], cur_e = w.cur_e[i];
+    float nxt_s = w.nxt_s[i], nxt_e = w.nxt_e[i];
+    bool live_s = w.live_s[i], live_e = w.live_e[i];
+    int it = w.it[i], k = w.k[i];
+    const int32_t ss = w.slot_s[i], se = w.slot_e[i];
+    if (ss >= 0) nxt_s = w.vals[ss];
+    if (se >= 0) nxt_e = w.vals[se];
+    int32_t *cursor = w.cnt + C_ROUND0 + round;
+    int32_t new_ss = -1, new_se = -1;
+    const bool first = (st == ST_WAIT_FIRST);
+    bool over_s = false, over_e = false;
+    // a ray moves through at most: LS-result -> LS-check -> top-of-loop -> march, i.e. 2 passes
+    for (int pass = 0; pass < 3; ++pass) {
+        if (st == ST_WAIT_FIRST) {
+            // top of the reference's while-loop: threshold, update masks, maybe stop, else march
+            cur_s = live_s ? nxt_s : 0.0f;
+            if (cur_s <= a.thr) cur_s = 0.0f;
+            cur_e = live_e ? nxt_e : 0.0f;
+            if (cur_e <= a.thr) cur_e = 0.0f;
+            live_s = live_s && (cur_s > a.thr);
+            live_e = live_e && (cur_e > a.thr);
+            if (first && pass == 0 && (live_s || live_e)) atomicOr(w.cnt + C_ANY_LIVE, 1);
+            if (!(live_s || live_e) || it == a.max_it) {
+                st = ST_DONE;
+                break;
+            }
+            ++it;
+            t_s = __fadd_rn(t_s, cur_s);
+            t_e = __fsub_rn(t_e, cur_e);
+            nxt_s = 0.0f;
+            nxt_e = 0.0f;
+            if (live_s) new_ss = append_point(a, cursor, i, t_s);
+            if (live_e) new_se = append_point(a, cursor, i, t_e);
+            st = ST_WAIT_MARCH;
+            break;
+        }
+        if (st == ST_WAIT_MARCH) {
+            k = 0;
+        } else {  // ST_WAIT_LS
+            ++k;
+        }
+        over_s = nxt_s < 0.0f;
+        over_e = nxt_e < 0.0f;
+        if (k < a.ls_iters && (over_s || over_e)) {
+            // pull a step that landed inside the surface back by (1 - step)/2^k of the last move
+            const float back = a.back[k];
+            if (over_s) {
+                t_s = __fsub_rn(t_s, __fmul_rn(back, cur_s));
+                new_ss = append_point(a, cursor, i, t_s);
+            }
+            if (over_e) {
+                t_e = __fadd_rn(t_e, __fmul_rn(back, cur_e));
+                new_se = append_point(a, cursor, i, t_e);
+            }
+            st = ST_WAIT_LS;
+            break;
+        }
+        const bool crossed = t_s < t_e;
+        live_s = live_s && crossed;
+        live_e = live_e && crossed;
+        st = ST_WAIT_FIRST;  // fall through to the top of the loop with the values we already hold
+    }
+    w.stage[i] = st;
+    w.t_s[i] = t_s; w.t_e[i] = t_e; w.cur_s[i] = cur_s; w.cur_e[i] = cur_e;
+    w.nxt_s[i] = nxt_s; w.nxt_e[i] = nxt_e;
+    w.live_s[i] = live_s; w.live_e[i] = live_e;
+    w.it[i] = (uint8_t)it; w.k[i] = (uint8_t)k;
+    w.slot_s[i] = new_ss; w.slot_e[i] = new_se;
+}
+
+// after the march: network mask, provisional outputs, hand unconverged rays to the sampler
+__global__ __launch_bounds__(kTB) void trace_finalize_kernel(TraceArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * kTB + threadIdx.x;
+    if (i >= a.n) return;
+    const TraceWs &w = a.w;
+    if (w.stage[i] != ST_DONE) atomicAdd(w.cnt + C_UNFINISHED, 1);
+    const float t_s = w.t_s[i], t_e = w.t_e[i];
+    a.out_mask[i] = t_s < t_e;
+    a.out_t[i] = t_s;
+    float px = 0.0f, py = 0.0f, pz = 0.0f;
+    // the reference recomputes cam + t*dir for ALL rays once its loop has run at least one iteration
+    if (a.hit[i] || w.cnt[C_ANY_LIVE]) along(a, i, t_s, px, py, pz);
+    a.out_pts[i * 3] = px; a.out_pts[i * 3 + 1] = py; a.out_pts[i * 3 + 2] = pz;
+    const bool samp = w.live_s[i] != 0;
+    w.is_samp[i] = samp;
+    if (samp) w.list_samp[atomicAdd(w.cnt + C_NSAMP, 1)] = (int32_t)i;
+}
+
+// n_steps samples along every listed ray: t = lo + f*(hi - lo)  (ray_tracing.py:198-206, 277-286)
+__global__ __launch_bounds__(kTB) void ray_samples_kernel(TraceArgs a, const int32_t *list, int c_n, int c_npts,
+                                                          const float *lo_arr, const float *hi_arr,
+                                                          const float *fr) {
+    const int64_t gid = (int64_t)blockIdx.x * kTB + threadIdx.x;
+    const TraceWs &w = a.w;
+    const int32_t n_list = w.cnt[c_n];
+    if (gid == 0) w.cnt[c_npts] = n_list * a.n_steps;
+    const int64_t m = gid / a.n_steps;
+    if (m >= n_list) return;
+    const int s = (int)(gid - m * a.n_steps);
+    const int64_t i = list[m];
+    const float lo = lo_arr[i], hi = hi_arr[i];
+    const float t = __fadd_rn(lo, __fmul_rn(fr[s], __fsub_rn(hi, lo)));
+    float px, py, pz;
+    along(a, i, t, px, py, pz);
+    w.pts[gid * 3] = px; w.pts[gid * 3 + 1] = py; w.pts[gid * 3 + 2] = pz;
+}
+
+__device__ __forceinline__ float secant_z(float v_lo, float v_hi, float z_lo, float z_hi) {
+    // - sdf_low * (z_high - z_low) / (sdf_high - sdf_low) + z_low, evaluated left to right
+    return __fadd_rn(__fdiv_rn(__fmul_rn(-v_lo, __fsub_rn(z_hi, z_lo)), __fsub_rn(v_hi, v_lo)), z_lo);
+}
+
+// first sign change / minimal sample per sampler ray, secant bracket set-up (ray_tracing.py:212-247)
+__global__ __launch_bounds__(kTB) void sampler_reduce_kernel(TraceArgs a) {
+    const int64_t m = (int64_t)blockIdx.x * kTB + threadIdx.x;
+    const TraceWs &w = a.w;
+    if (m >= w.cnt[C_NSAMP]) return;
+    const int64_t i = w.list_samp[m];
+    const int n = a.n_steps;
+    const float *v = w.vals + m * n;
+    int first = 0, amin = 0;
+    float best_tmp = 0.0f, best_v = 0.0f;
+    for (int s = 0; s < n; ++s) {
+        const float x = v[s];
+        const float sg = (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f);
+        const float tmp = sg * (float)(n - s);  // sign(sdf) * arange(n, 0, -1)
+        if (s == 0 || tmp < best_tmp) { best_tmp = tmp; first = s; }
+        if (s == 0 || x < best_v) { best_v = x; amin = s; }
+    }
+    const float lo = w.t_s[i], hi = w.t_e[i];
+    auto t_at = [&](int s) { return __fadd_rn(lo, __fmul_rn(a.fracs[s], __fsub_rn(hi, lo))); };
+    const float v_first = v[first];
+    const bool net_hit = v_first < 0.0f;
+    const bool true_obj = a.obj[i] != 0;
+    const int pick = (true_obj && net_hit) ? first : amin;
+    float t_out = t_at(pick);
+    float px, py, pz;
+    along(a, i, t_out, px, py, pz);
+    a.out_mask[i] = net_hit;
+    const bool sec = a.training ? (net_hit && true_obj) : net_hit;
+    if (sec) {
+        const int lo_idx = first > 0 ? first - 1 : n - 1;  // index -1 wraps to the last sample, as in the reference
+        const float z_hi = t_at(first), v_hi = v_first, z_lo = t_at(lo_idx), v_lo = v[lo_idx];
+        const float z = secant_z(v_lo, v_hi, z_lo, z_hi);
+        const int32_t q = atomicAdd(w.cnt + C_NSEC, 1);
+        w.list_sec[q] = (int32_t)i;
+        w.z_lo[q] = z_lo; w.z_hi[q] = z_hi; w.v_lo[q] = v_lo; w.v_hi[q] = v_hi; w.z[q] = z;
+        if (a.n_secant == 0) {  // no refinement rounds: the initial secant estimate is the answer
+            t_out = z;
+            along(a, i, z, px, py, pz);
+        }
+    }
+    a.out_t[i] = t_out;
+    w.t_s[i] = t_out;
+    a.out_pts[i * 3] = px; a.out_pts[i * 3 + 1] = py; a.out_pts[i * 3 + 2] = pz;
+}
+
+// p_mid = cam + z*dir for every secant ray (the points of the next SDF launch)
+__global__ __launch_bounds__(kTB) void secant_points_kernel(TraceArgs a) {
+    const int64_t q = (int64_t)blockIdx.x * kTB + threadIdx.x;
+    const TraceWs &w = a.w;
+    if (q >= w.cnt[C_NSEC]) return;
+    float px, py, pz;
+    along(a, w.list_sec[q], w.z[q], px, py, pz);
+    w.pts[q * 3] = px; w.pts[q * 3 + 1] = py; w.pts[q * 3 + 2] = pz;
+}
+
+// one secant iteration (ray_tracing.py:255-266); the last one writes the refined hit
+__global__ __launch_bounds__(kTB) void secant_advance_kernel(TraceArgs a, int last) {
+    const int64_t q = (int64_t)blockIdx.x * kTB + threadIdx.x;
+    const TraceWs &w = a.w;
+    if (q >= w.cnt[C_NSEC]) return;
+    const float v = w.vals[q];
+    float z = w.z[q], z_lo = w.z_lo[q], z_hi = w.z_hi[q], v_lo = w.v_lo[q], v_hi = w.v_hi[q];
+    if (v > 0.0f) { z_lo = z; v_lo = v; }
+    if (v < 0.0f) { z_hi = z; v_hi = v; }
+    z = secant_z(v_lo, v_hi, z_lo, z_hi);
+    w.z[q] = z; w.z_lo[q] = z_lo; w.z_hi[q] = z_hi; w.v_lo[q] = v_lo; w.v_hi[q] = v_hi;
+    const int64_t i = w.list_sec[q];
+    float px, py, pz;
+    along(a, i, z, px, py, pz);
+    if (last) {
+        a.out_t[i] = z;
+        w.t_s[i] = z;
+        a.out_pts[i * 3] = px; a.out_pts[i * 3 + 1] = py; a.out_pts[i * 3 + 2] = pz;
+    } else {
+        w.pts[q * 3] = px; w.pts[q * 3 + 1] = py; w.pts[q * 3 + 2] = pz;
+    }
+}
+
+// training tail, part 1 (ray_tracing.py:71-88): rays that feed the mask loss
+__global__ __launch_bounds__(kTB) void tail_prepare_kernel(TraceArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * kTB + threadIdx.x;
+    if (i >= a.n) return;
+    const TraceWs &w = a.w;
+    const bool net = a.out_mask[i] != 0, obj = a.obj[i] != 0, samp = w.is_samp[i] != 0, hit = a.hit[i] != 0;
+    const bool in_mask = !net && obj && !samp;
+    const bool out_mask = !obj && !samp;
+    if (!(in_mask || out_mask)) return;
+    if (!hit) {
+        // the ray never enters the sphere: closest point of the ray to the origin, t = -<dir, cam>
+        const float *c = a.cam + (i / a.rays_per_image) * 3;
+        const float *d = a.dirs + i * 3;
+        const float dot = __fmaf_rn(d[2], c[2], __fmaf_rn(d[1], c[1], __fmul_rn(d[0], c[0])));
+        const float t = -dot;
+        float px, py, pz;
+        along(a, i, t, px, py, pz);
+        a.out_t[i] = t;
+        w.t_s[i] = t;
+        a.out_pts[i * 3] = px; a.out_pts[i * 3 + 1] = py; a.out_pts[i * 3 + 2] = pz;
+        return;
+    }
+    if (net && out_mask) w.t_min[i] = w.t_s[i];
+    w.list_sel[atomicAdd(w.cnt + C_NSEL, 1)] = (int32_t)i;
+}
+
+// training tail, part 2 (ray_tracing.py:288-296): argmin of the SDF over the shared random fractions
+__global__ __launch_bounds__(kTB) void closest_reduce_kernel(TraceArgs a) {
+    const int64_t m = (int64_t)blockIdx.x * kTB + threadIdx.x;
+    const TraceWs &w = a.w;
+    if (m >= w.cnt[C_NSEL]) return;
+    const int64_t i = w.list_sel[m];
+    const int n = a.n_steps;
+    const float *v = w.vals + m * n;
+    int amin = 0;
+    float best = v[0];
+    for (int s = 1; s < n; ++s)
+        if (v[s] < best) { best = v[s]; amin = s; }
+    const float lo = w.t_min[i], hi = w.t_max[i];
+    const float t = __fadd_rn(__fmul_rn(a.steps_u[amin], __fsub_rn(hi, lo)), lo);
+    float px, py, pz;
+    along(a, i, t, px, py, pz);
+    a.out_t[i] = t;
+    a.out_pts[i * 3] = px; a.out_pts[i * 3 + 1] = py; a.out_pts[i * 3 + 2] = pz;
+}
+
+__global__ void count_evals_kernel(int32_t *cnt, int rounds, int n_secant) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int64_t tot = 0;
+    for (int r = 0; r < rounds && r < 64; ++r) tot += cnt[C_ROUND0 + r];
+    tot += cnt[C_NSAMP_PTS] + (int64_t)cnt[C_NSEC] * n_secant + cnt[C_NSEL_PTS];
+    cnt[C_EVALS] = (int32_t)tot;
+}
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Layout {
+    size_t off_f, off_i, off_b, off_pts, off_vals, off_cnt, total;
+    int64_t cap;
+};
+
+Layout make_layout(int64_t n, int n_steps) {
+    Layout L;
+    L.cap = n * (n_steps > 2 ? n_steps : 2);
+    size_t o = 0;
+    L.off_f = o; o = align_up(o + sizeof(float) * 13 * (size_t)n, 256);
+    L.off_i = o; o = align_up(o + sizeof(int32_t) * 5 * (size_t)n, 256);
+    L.off_b = o; o = align_up(o + 6 * (size_t)n, 256);
+    L.off_pts = o; o = align_up(o + sizeof(float) * 3 * (size_t)L.cap, 256);
+    L.off_vals = o; o = align_up(o + sizeof(float) * (size_t)L.cap, 256);
+    L.off_cnt = o; o = align_up(o + sizeof(int32_t) * C_COUNT, 256);
+    L.total = o;
+    return L;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t hm_trace_workspace_bytes(int64_t n_rays, const hm_trace_cfg *cfg) {
+    if (n_rays < 0 || !cfg || cfg->n_steps < 1) return hm_fail(HM_ERR_INVALID, "hm_trace_workspace_bytes: bad argument");
+    return (int64_t)make_layout(n_rays, cfg->n_steps).total;
+}
+
+int hm_trace_forward(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *table, const float *B_fourier,
+                     int frac_mode, int tile_points, const hm_trace_cfg *cfg, const float *cam_loc,
+                     const float *ray_dirs, const uint8_t *object_mask, const float *t_sphere,
+                     const uint8_t *hit_mask, int64_t n_rays, int64_t rays_per_image, const float *sampler_fracs,
+                     const float *steps_u, float *out_points, uint8_t *out_net_mask, float *out_dists,
+                     void *workspace, int64_t workspace_bytes, int32_t *stats_out, void *stream) {
+    HM_CHECK_ARG(desc && mlp && cfg, "hm_trace_forward: NULL descriptor");
+    HM_CHECK_ARG(n_rays >= 0 && rays_per_image >= 1, "hm_trace_forward: bad ray counts");
+    HM_CHECK_ARG(cfg->n_steps >= 2 && cfg->n_steps <= 4096, "hm_trace_forward: n_steps out of range");
+    HM_CHECK_ARG(cfg->sphere_tracing_iters >= 0 && cfg->sphere_tracing_iters <= 15 && cfg->line_step_iters >= 0 &&
+                     cfg->line_step_iters <= 3 &&
+                     1 + cfg->sphere_tracing_iters * (1 + cfg->line_step_iters) <= 64,
+                 "hm_trace_forward: too many march rounds (sphere_tracing_iters <= 15, line_step_iters <= 3)");
+    HM_CHECK_ARG(cfg->n_secant_steps >= 0 && cfg->n_secant_steps <= 64, "hm_trace_forward: n_secant_steps out of range");
+    if (n_rays == 0) return HM_OK;
+    HM_CHECK_ARG(n_rays * (int64_t)cfg->n_steps < (1ll << 31), "hm_trace_forward: too many rays for one call");
+    HM_CHECK_ARG(table && B_fourier && cam_loc && ray_dirs && object_mask && t_sphere && hit_mask && sampler_fracs &&
+                     out_points && out_net_mask && out_dists && workspace,
+                 "hm_trace_forward: NULL pointer");
+    HM_CHECK_ARG(!cfg->training || steps_u, "hm_trace_forward: training mode needs steps_u");
+    const Layout L = make_layout(n_rays, cfg->n_steps);
+    HM_CHECK_ARG(workspace_bytes >= (int64_t)L.total, "hm_trace_forward: workspace too small");
+    hipStream_t st = as_stream(stream);
+    char *base = static_cast<char *>(workspace);
+    const size_t n = (size_t)n_rays;
+    TraceArgs a;
+    float *f = reinterpret_cast<float *>(base + L.off_f);
+    a.w.t_s = f; a.w.t_e = f + n; a.w.t_min = f + 2 * n; a.w.t_max = f + 3 * n; a.w.cur_s = f + 4 * n;
+    a.w.cur_e = f + 5 * n; a.w.nxt_s = f + 6 * n; a.w.nxt_e = f + 7 * n; a.w.z_lo = f + 8 * n; a.w.z_hi = f + 9 * n;
+    a.w.v_lo = f + 10 * n; a.w.v_hi = f + 11 * n; a.w.z = f + 12 * n;
+    int32_t *ip = reinterpret_cast<int32_t *>(base + L.off_i);
+    a.w.slot_s = ip; a.w.slot_e = ip + n; a.w.list_samp = ip + 2 * n; a.w.list_sec = ip + 3 * n; a.w.list_sel = ip + 4 * n;
+    uint8_t *bp = reinterpret_cast<uint8_t *>(base + L.off_b);
+    a.w.live_s = bp; a.w.live_e = bp + n; a.w.stage = bp + 2 * n; a.w.it = bp + 3 * n; a.w.k = bp + 4 * n;
+    a.w.is_samp = bp + 5 * n;
+    a.w.pts = reinterpret_cast<float *>(base + L.off_pts);
+    a.w.vals = reinterpret_cast<float *>(base + L.off_vals);
+    a.w.cnt = reinterpret_cast<int32_t *>(base + L.off_cnt);
+    a.w.cap = L.cap;
+    a.cam = cam_loc; a.dirs = ray_dirs; a.obj = object_mask; a.t_sphere = t_sphere; a.hit = hit_mask;
+    a.fracs = sampler_fracs; a.steps_u = steps_u;
+    a.out_pts = out_points; a.out_mask = out_net_mask; a.out_t = out_dists;
+    a.n = n_rays; a.rays_per_image = rays_per_image;
+    a.thr = cfg->sdf_threshold;
+    for (int k = 0; k < 4; ++k) a.back[k] = (float)((1.0 - cfg->line_search_step) / (double)(1 << k));
+    a.ls_iters = cfg->line_step_iters; a.max_it = cfg->sphere_tracing_iters; a.n_steps = cfg->n_steps;
+    a.n_secant = cfg->n_secant_steps; a.training = cfg->training;
+
+    hipError_t e = hipMemsetAsync(a.w.cnt, 0, sizeof(int32_t) * C_COUNT, st);
+    if (e != hipSuccess) return hm_fail(HM_ERR_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e));
+    const unsigned g_rays = (unsigned)((n_rays + kTB - 1) / kTB);
+    const unsigned g_samp = (unsigned)((n_rays * cfg->n_steps + kTB - 1) / kTB);
+
+    auto sdf = [&](int64_t capacity, const int32_t *n_dev) -> int {
+        return hm_sdf_fwd(desc, mlp, a.w.pts, capacity, table, B_fourier, a.w.vals, 1, 1, frac_mode, tile_points, n_dev,
+                          0, stream);
+    };
+
+    // ---- 1. bidirectional sphere tracing: one state-machine round per SDF launch -------------------
+    hipLaunchKernelGGL(trace_init_kernel, dim3(g_rays), dim3(kTB), 0, st, a);
+    const int rounds = 1 + cfg->sphere_tracing_iters * (1 + cfg->line_step_iters);
+    for (int r = 0; r < rounds; ++r) {
+        int rc = sdf(2 * n_rays, a.w.cnt + C_ROUND0 + r);
+        if (rc != HM_OK) return rc;
+        // round r+1 cursor (the last advance appends nothing that is evaluated; it only closes states)
+        hipLaunchKernelGGL(trace_advance_kernel, dim3(g_rays), dim3(kTB), 0, st, a, r + 1 < 64 ? r + 1 : 63);
+    }
+    hipLaunchKernelGGL(trace_finalize_kernel, dim3(g_rays), dim3(kTB), 0, st, a);
+
+    // ---- 2. sampler + secant for rays that did not converge ----------------------------------------
+    hipLaunchKernelGGL(ray_samples_kernel, dim3(g_samp), dim3(kTB), 0, st, a, a.w.list_samp, (int)C_NSAMP,
+                       (int)C_NSAMP_PTS, a.w.t_s, a.w.t_e, sampler_fracs);
+    {
+        int rc = sdf(n_rays * cfg->n_steps, a.w.cnt + C_NSAMP_PTS);
+        if (rc != HM_OK) return rc;
+    }
+    hipLaunchKernelGGL(sampler_reduce_kernel, dim3(g_rays), dim3(kTB), 0, st, a);
+    if (cfg->n_secant_steps > 0) {
+        hipLaunchKernelGGL(secant_points_kernel, dim3(g_rays), dim3(kTB), 0, st, a);
+        for (int s = 0; s < cfg->n_secant_steps; ++s) {
+            int rc = sdf(n_rays, a.w.cnt + C_NSEC);
+            if (rc != HM_OK) return rc;
+            hipLaunchKernelGGL(secant_advance_kernel, dim3(g_rays), dim3(kTB), 0, st, a,
+                               s == cfg->n_secant_steps - 1 ? 1 : 0);
+        }
+    }
+
+    // ---- 3. training only: closest approach for the mask-loss rays --------------------------------
+    if (cfg->training) {
+        hipLaunchKernelGGL(tail_prepare_kernel, dim3(g_rays), dim3(kTB), 0, st, a);
+        hipLaunchKernelGGL(ray_samples_kernel, dim3(g_samp), dim3(kTB), 0, st, a, a.w.list_sel, (int)C_NSEL,
+                           (int)C_NSEL_PTS, a.w.t_min, a.w.t_max, steps_u);
+        int rc = sdf(n_rays * cfg->n_steps, a.w.cnt + C_NSEL_PTS);
+        if (rc != HM_OK) return rc;
+        hipLaunchKernelGGL(closest_reduce_kernel, dim3(g_rays), dim3(kTB), 0, st, a);
+    }
+    hipLaunchKernelGGL(count_evals_kernel, dim3(1), dim3(64), 0, st, a.w.cnt, rounds + 1, cfg->n_secant_steps);
+    if (stats_out) {
+        e = hipMemcpyAsync(stats_out, a.w.cnt + C_NSAMP, sizeof(int32_t) * 8, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return hm_fail(HM_ERR_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e));
+    }
+    HM_CHECK_LAUNCH("hm_trace_forward");
+    return HM_OK;
+}
+
+}  // extern "C"

@@ -18,6 +18,7 @@ reference makes (``torch.empty(n).uniform_(0, 1)``) unless ``steps`` is injected
 import torch
 import torch.nn as nn
 
+from .. import _lib, ops
 from ..utils import rend_util
 
 
@@ -34,10 +35,67 @@ class RayTracing(nn.Module):
         self.n_secant_steps = n_secant_steps
         self.verbose = False      # the reference prints three lines per call (:61-64), each a device sync
         self.steps_override = None  # optional [n_steps] tensor replacing the U(0,1) draw of step 3
-        self.last_stats = {}
+        self.use_device_tracer = True   # sync-free HIP state-machine tracer when `sdf` is the package's network
+        self._stats = {}
+        self._stats_dev = None
+        self._ws = None
+
+    @property
+    def last_stats(self):
+        """Counters of the last call (reads them back from the device on access)."""
+        if self._stats_dev is not None:
+            v = self._stats_dev.tolist()
+            self._stats = {"rays": self._stats.get("rays"), "sampler_rays": v[0], "secant_rays": v[2],
+                           "mask_loss_rays": v[3], "sdf_evals": v[6], "unfinished": v[7]}
+            self._stats_dev = None
+        return self._stats
+
+    def _fused_network(self, sdf, ray_directions):
+        net = getattr(sdf, "__self__", None)
+        if (self.use_device_tracer and net is not None and ray_directions.is_cuda and hasattr(net, "packed_weights")
+                and getattr(sdf, "__func__", None) is getattr(type(net), "sdf", None) and net._fusable()):
+            return net
+        return None
+
+    def _forward_device(self, net, cam_loc, object_mask, ray_directions):
+        """The whole search enqueued by ONE C-ABI call (csrc/hm_trace.hip); no host synchronisation."""
+        B, P, _ = ray_directions.shape
+        N = B * P
+        dev = ray_directions.device
+        with torch.no_grad():
+            t_sphere, hit = rend_util.get_sphere_intersection(cam_loc.detach(), ray_directions.detach(),
+                                                              r=self.object_bounding_sphere)
+            cfg = _lib.TraceCfg(float(self.object_bounding_sphere), float(self.sdf_threshold),
+                                float(self.line_search_step), int(self.line_step_iters),
+                                int(self.sphere_tracing_iters), int(self.n_steps), int(self.n_secant_steps),
+                                1 if self.training else 0)
+            need = ops.trace_workspace_bytes(N, cfg)
+            if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+                self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            steps_u = None
+            if self.training:
+                if self.steps_override is not None:
+                    steps_u = self.steps_override.to(dev).float().contiguous()
+                else:
+                    # same generator call as the reference (:277); it is made even when no ray ends up needing it
+                    steps_u = torch.empty(self.n_steps).uniform_(0.0, 1.0).to(dev)
+            emb = net._hash_embedder()
+            stats = torch.zeros(8, dtype=torch.int32, device=dev)
+            pts, mask, dists = ops.trace_forward(
+                emb.desc, net.packed_weights(), emb.table.detach(), emb.freq_encoding.B,
+                ops.FRAC_MODES[emb.frac_mode], net.sdf_tile_points, cfg, cam_loc.detach().contiguous().float(),
+                ray_directions.detach().reshape(N, 3).contiguous().float(),
+                object_mask.reshape(N).to(torch.uint8).contiguous(), t_sphere.reshape(N, 2).contiguous(),
+                hit.reshape(N).to(torch.uint8).contiguous(), P, self._linspace(dev), steps_u, self._ws, stats)
+        self._stats = {"rays": N}
+        self._stats_dev = stats
+        return pts, mask.bool(), dists
 
     # ------------------------------------------------------------------------------------
     def forward(self, sdf, cam_loc, object_mask, ray_directions):
+        net = self._fused_network(sdf, ray_directions)
+        if net is not None:
+            return self._forward_device(net, cam_loc, object_mask, ray_directions)
         B, P, _ = ray_directions.shape
         N = B * P
         dirs = ray_directions.reshape(N, 3)
@@ -61,7 +119,7 @@ class RayTracing(nn.Module):
             t_start[idx] = s_t
             net_mask[idx] = s_hit
             n_secant_hits = int(s_hit.sum())
-        self.last_stats = {"rays": N, "sampler_rays": n_sampler}
+        self._stats, self._stats_dev = {"rays": N, "sampler_rays": n_sampler}, None
         if self.verbose:
             print('----------------------------------------------------------------')
             print('RayTracing: object = {0}/{1}, secant on {2}/{3}.'.format(int(net_mask.sum()), N, n_secant_hits,

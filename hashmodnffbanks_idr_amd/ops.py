@@ -305,3 +305,27 @@ def sdf_fwd(desc, packed, x, table, B, frac_mode=0, sdf_only=False, max_workgrou
                            dptr(out), cols, cols, int(frac_mode), int(tile_points), dptr(n_dev),
                            int(max_workgroups), stream_ptr(x)))
     return out[:, 0] if sdf_only else out
+
+
+# =========================================================================================
+# sync-free ray tracer (csrc/hm_trace.hip)
+# =========================================================================================
+def trace_workspace_bytes(n_rays, cfg):
+    return check(lib().hm_trace_workspace_bytes(int(n_rays), C.byref(cfg)))
+
+
+def trace_forward(desc, packed, table, B, frac_mode, tile_points, cfg, cam_loc, ray_dirs, object_mask, t_sphere,
+                  hit_mask, rays_per_image, sampler_fracs, steps_u, workspace, stats=None):
+    """Enqueues the whole intersection search (no host sync).  Returns (points, net_mask_u8, dists)."""
+    require_gpu(cam_loc, ray_dirs, object_mask, t_sphere, hit_mask, sampler_fracs, workspace)
+    n = ray_dirs.shape[0]
+    dev = ray_dirs.device
+    pts = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    mask = torch.empty((n,), dtype=torch.uint8, device=dev)
+    dists = torch.empty((n,), dtype=torch.float32, device=dev)
+    check(lib().hm_trace_forward(desc.handle, C.byref(packed.desc), dptr(table), dptr(B), int(frac_mode),
+                                 int(tile_points), C.byref(cfg), dptr(cam_loc), dptr(ray_dirs), dptr(object_mask),
+                                 dptr(t_sphere), dptr(hit_mask), n, int(rays_per_image), dptr(sampler_fracs),
+                                 dptr(steps_u), dptr(pts), dptr(mask), dptr(dists), dptr(workspace),
+                                 workspace.numel(), dptr(stats), stream_ptr(ray_dirs)))
+    return pts, mask, dists

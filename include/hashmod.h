@@ -138,6 +138,43 @@ HM_API int hm_sdf_fwd(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const fl
                       const float *table, const float *B_fourier, float *out, int64_t out_stride, int out_cols,
                       int frac_mode, int tile_points, const int32_t *n_dev, int max_workgroups, void *stream);
 
+/* ---- ray / surface intersection search ------------------------------------------------------
+ * Replaces RayTracing.forward and its helpers sphere_tracing / ray_sampler / secant /
+ * minimal_sdf_points (model/ray_tracing.py:26-298) when the `sdf` callable is the network above:
+ * bidirectional sphere tracing with line-search back-off, the n_steps sign-change sampler with
+ * n_secant_steps secant iterations for rays that did not converge, and (training) the
+ * closest-approach search for the mask-loss rays.  Same constructor values as the reference
+ * class (ray_tracing.py:6-24); `training` = self.training.  One call enqueues the whole search
+ * on `stream` without any host synchronisation (per-ray state machines + device-side compaction).
+ *
+ * cam_loc [B,3]; ray_dirs [N,3] (N = B*rays_per_image); object_mask [N] bytes;
+ * t_sphere [N,2] / hit_mask [N]: near/far parameters and hit flags of the bounding sphere
+ *   (utils/rend_util.py:141-162, computed by the caller);
+ * sampler_fracs [n_steps] = linspace(0,1,n_steps) (ray_tracing.py:198);
+ * steps_u [n_steps]: the U(0,1) fractions shared by all rays (ray_tracing.py:277; training only);
+ * outputs: points [N,3], network_object_mask [N] bytes, dists [N];
+ * stats_out (optional, 8 device int32): sampler rays, sampler points, secant rays, mask-loss rays,
+ *   their points, any-iteration flag, total SDF evaluations, unfinished rays (must be 0).          */
+typedef struct hm_trace_cfg {
+    float object_bounding_sphere;
+    float sdf_threshold;
+    double line_search_step;       /* back-off factors (1-step)/2^k are formed in double, like the reference */
+    int32_t line_step_iters;       /* <= 3  */
+    int32_t sphere_tracing_iters;  /* <= 15 */
+    int32_t n_steps;
+    int32_t n_secant_steps;
+    int32_t training;
+} hm_trace_cfg;
+
+HM_API int64_t hm_trace_workspace_bytes(int64_t n_rays, const hm_trace_cfg *cfg);
+HM_API int hm_trace_forward(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *table,
+                            const float *B_fourier, int frac_mode, int tile_points, const hm_trace_cfg *cfg,
+                            const float *cam_loc, const float *ray_dirs, const uint8_t *object_mask,
+                            const float *t_sphere, const uint8_t *hit_mask, int64_t n_rays, int64_t rays_per_image,
+                            const float *sampler_fracs, const float *steps_u, float *out_points,
+                            uint8_t *out_net_mask, float *out_dists, void *workspace, int64_t workspace_bytes,
+                            int32_t *stats_out, void *stream);
+
 /* ---- exact-fp32 GEMM (grad-enabled MLP path) ------------------------------------------------
  * Replaces the nn.Linear matmuls autograd runs for the SDF and rendering MLPs when gradients are
  * needed (implicit_differentiable_renderer.py:102,116-128,211-221): forward X*W^T + b, backward

@@ -60,3 +60,47 @@ def test_sphere_intersection_golden(golden):
                                              torch.from_numpy(g["ray_dirs"]).cuda(), r=1.0)
     assert np.array_equal(m.cpu().numpy(), g["mask_intersect"])
     np.testing.assert_allclose(t.cpu().numpy(), g["sphere_intersections"], rtol=1e-6, atol=1e-6)
+
+
+def _device_vs_host(tag, golden, mode, n_rays=None, seed=0):
+    """The sync-free device tracer must reproduce the generic (torch op) tracer when both use the
+    same SDF kernel tile size (so the SDF values are bit-identical)."""
+    from hashmodnffbanks_idr_amd.model.ray_tracing import RayTracing
+    import params as P
+    g = golden(f"raytrace_{tag}")
+    net = make_implicit("C1", (512,) * 8, 256, int(g["seed"]), float(g["perturb"]), float(g["table_scale"]))
+    net.eval()
+    net.sdf_tile_points = 64
+    if n_rays is None:
+        cam, dirs, om = g["cam_loc"], g["ray_dirs"], g["object_mask"]
+    else:
+        cam, dirs = P.make_rays(seed, n_rays)
+        om = np.random.RandomState(seed).uniform(0, 1, n_rays) < 0.7
+    outs = []
+    for dev_tracer in (True, False):
+        rt = RayTracing(1.0, 5.0e-5, 0.5, 3, 10, 100, 8).cuda()
+        rt.train(mode == "train")
+        rt.use_device_tracer = dev_tracer
+        rt.steps_override = torch.from_numpy(g["steps"])
+        with torch.no_grad():
+            outs.append(rt(sdf=net.sdf, cam_loc=torch.from_numpy(cam).cuda(), object_mask=torch.from_numpy(om).cuda(),
+                           ray_directions=torch.from_numpy(dirs).cuda()))
+        if dev_tracer:
+            st = rt.last_stats
+            assert st["unfinished"] == 0
+    (p1, m1, d1), (p2, m2, d2) = outs
+    assert torch.equal(m1, m2)
+    assert torch.equal(d1, d2), (d1 - d2).abs().max()
+    assert torch.equal(p1, p2), (p1 - p2).abs().max()
+    return st
+
+
+@pytest.mark.parametrize("tag", ["init", "bumpy"])
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_device_tracer_equals_generic_tracer(golden, tag, mode):
+    _device_vs_host(tag, golden, mode)
+
+
+def test_device_tracer_equals_generic_tracer_2048_rays(golden):
+    st = _device_vs_host("bumpy", golden, "train", n_rays=2048, seed=11)
+    assert st["sdf_evals"] > 2048 * 20
