@@ -157,17 +157,14 @@ def mlp_roofline(net, log2_n=18, iters=5, warmup=2):
             "points_per_s": round(n / (avg_ms * 1e-3), 1)}
 
 
-def cpu_baseline(n_rays=256, reps=2):
-    """oracle/torch_ref.py (port of the reference's PyTorch path) on the host cores, same workload
-    shape at a bounded ray count: forward + IDRLoss + backward."""
+def cpu_baseline(model, n_rays=256, reps=2):
+    """oracle/torch_ref.py (port of the reference's PyTorch path) on the host cores: the SAME
+    parameters the GPU run ended with (so both see the same surface / amount of ray-marching work),
+    same workload shape at a bounded ray count: forward + IDRLoss + backward."""
     from oracle import torch_ref as R
-    from hashmodnffbanks_idr_amd.model.implicit_differentiable_renderer import IDRNetwork
     from hashmodnffbanks_idr_amd.model.loss import IDRLoss
-    torch.manual_seed(0)
-    model = IDRNetwork(idr_conf(CFG)).cpu()
     ref = R.RefIDR(model)
     ref.train()
-    del model
     inp, gt = synthetic_batch(1234, n_rays, "cpu")
     loss_fn = IDRLoss(eikonal_weight=0.1, mask_weight=100.0, alpha=50.0)
     cores = torch.get_num_threads()
@@ -253,7 +250,7 @@ def main():
             emb = model.implicit_network.embed_model.embedder_obj
             line["roofline"] = gather_roofline(emb, args.gather_log2n)
             line["roofline_mlp"] = mlp_roofline(model.implicit_network)
-            line["cpu_baseline"] = cpu_baseline()
+            line["cpu_baseline"] = cpu_baseline(model)
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()
