@@ -35,11 +35,17 @@ def _weight_normed(lin):
         return nn.utils.weight_norm(lin)
 
 
-def _folded_weight(lin):
-    """W = g * v / ||v||_row for weight-normed layers (nn.utils.weight_norm, dim=0), else lin.weight."""
-    if hasattr(lin, "weight_g"):
-        return torch._weight_norm(lin.weight_v, lin.weight_g, 0)
-    return lin.weight
+def _folded_weight(lin, cache=None):
+    """W = g * v / ||v||_row for weight-normed layers (nn.utils.weight_norm, dim=0), else lin.weight.
+    `cache` (a dict living for ONE IDRNetwork.forward) shares the fold between the evaluations of a step."""
+    if not hasattr(lin, "weight_g"):
+        return lin.weight
+    if cache is not None and torch.is_grad_enabled():
+        w = cache.get(id(lin))
+        if w is None:
+            w = cache[id(lin)] = torch._weight_norm(lin.weight_v, lin.weight_g, 0)
+        return w
+    return torch._weight_norm(lin.weight_v, lin.weight_g, 0)
 
 
 class ImplicitNetwork(nn.Module):
@@ -90,6 +96,7 @@ class ImplicitNetwork(nn.Module):
             p.requires_grad = True
         self._packed = None
         self._packed_key = None
+        self._fold_cache = None
         self.sdf_tile_points = 0  # fused kernel tile: 0 auto (16-point tiles for small batches), 16, 64
 
     # ---- fused no-grad path ---------------------------------------------------------------
@@ -150,7 +157,7 @@ class ImplicitNetwork(nn.Module):
             lin = getattr(self, "lin" + str(l))
             if l in self.skip_in:
                 x = torch.cat([x, emb], 1) / np.sqrt(2)
-            x = ops.linear(x, _folded_weight(lin), lin.bias)
+            x = ops.linear(x, _folded_weight(lin, self._fold_cache), lin.bias)
             if l < self.num_layers - 2:
                 x = self.softplus(x)
         # soft clamp of the SDF column: tanh(s / (2 + LaplaceDensity(s))), density under no_grad
@@ -160,12 +167,18 @@ class ImplicitNetwork(nn.Module):
 
     def gradient(self, x):
         """d sdf / d x with the graph kept (create_graph=True) -> [N,1,3]."""
+        return self.forward_with_gradient(x)[1]
+
+    def forward_with_gradient(self, x):
+        """(forward(x) [N,1+fvs], d sdf/d x [N,1,3]) from ONE network evaluation; the reference
+        evaluates the network twice for this pair (get_rbg_value, :321-323) with identical values."""
         x.requires_grad_(True)
-        y = self.forward(x)[:, :1]
+        out = self.forward(x)
+        y = out[:, :1]
         d_output = torch.ones_like(y, requires_grad=False, device=y.device)
         gradients = torch.autograd.grad(outputs=y, inputs=x, grad_outputs=d_output, create_graph=True,
                                         retain_graph=True, only_inputs=True)[0]
-        return gradients.unsqueeze(1)
+        return out, gradients.unsqueeze(1)
 
 
 class RenderingNetwork(nn.Module):
@@ -204,6 +217,7 @@ class RenderingNetwork(nn.Module):
             setattr(self, "lin" + str(l), lin)
         self.relu = nn.ReLU()
         self.tanh = nn.Tanh()
+        self._fold_cache = None
         for p in self.parameters():
             p.requires_grad = True
 
@@ -218,7 +232,7 @@ class RenderingNetwork(nn.Module):
             x = torch.cat([points, view_dirs, feature_vectors], dim=-1)
         for l in range(self.num_layers - 1):
             lin = getattr(self, "lin" + str(l))
-            x = ops.linear(x, _folded_weight(lin), lin.bias)
+            x = ops.linear(x, _folded_weight(lin, self._fold_cache), lin.bias)
             if l < self.num_layers - 2:
                 x = self.relu(x)
         return self.tanh(x)
@@ -236,8 +250,21 @@ class IDRNetwork(nn.Module):
         self.ray_tracer = RayTracing(**conf.get_config('ray_tracer'))
         self.sample_network = SampleNetwork()
         self.object_bounding_sphere = conf.get_float('ray_tracer.object_bounding_sphere')
+        # one SDF-network evaluation per training forward instead of the reference's three (identical
+        # values; only legal while the ray points carry no camera gradient - checked per call)
+        self.merge_evaluations = True
 
     def forward(self, input):
+        cache = {}
+        self.implicit_network._fold_cache = cache
+        self.rendering_network._fold_cache = cache
+        try:
+            return self._forward(input)
+        finally:
+            self.implicit_network._fold_cache = None
+            self.rendering_network._fold_cache = None
+
+    def _forward(self, input):
         intrinsics = input["intrinsics"]
         uv = input["uv"]
         pose = input["pose"]
@@ -256,10 +283,30 @@ class IDRNetwork(nn.Module):
 
         # 2. re-express the hit points through (possibly learnable) camera parameters
         points = (cam_loc.unsqueeze(1) + dists.reshape(batch_size, num_pixels, 1) * ray_dirs).reshape(-1, 3)
-        sdf_output = self.implicit_network(points)[:, 0:1]
         ray_dirs = ray_dirs.reshape(-1, 3)
+        merged = self.training and self.merge_evaluations and torch.is_grad_enabled() and not points.requires_grad
 
-        if self.training:
+        if merged:
+            # Fixed cameras: the reference evaluates the SDF network on the ray points three times
+            # (:264 all rays, :286 surface subset, :289 again inside gradient()) plus the eikonal samples.
+            # The rows are independent, so ONE evaluation of [ray points ; eikonal samples] with
+            # create_graph yields the same sdf_output, surface values, surface gradients and grad_theta.
+            n_rays = batch_size * num_pixels
+            bb = self.object_bounding_sphere
+            eikonal_points = torch.empty(n_rays // 2, 3).uniform_(-bb, bb).to(dev)  # global CPU RNG, as the reference
+            x_all = torch.cat([points.detach(), eikonal_points], 0)
+            out_all, g_all = self.implicit_network.forward_with_gradient(x_all)
+            sdf_output = out_all[:n_rays, 0:1]
+            surface_mask = network_object_mask & object_mask
+            surface_output = sdf_output[surface_mask]
+            surface_sdf_values = surface_output.detach()
+            surface_points_grad = g_all[:n_rays, 0, :][surface_mask].clone().detach()
+            grad_theta = torch.cat([g_all[n_rays:, 0, :], g_all[:n_rays, 0, :]], 0)  # reference row order (:284,:291)
+            differentiable_surface_points = self.sample_network(
+                surface_output, surface_sdf_values, surface_points_grad, dists[surface_mask].unsqueeze(-1),
+                cam_loc.unsqueeze(1).repeat(1, num_pixels, 1).reshape(-1, 3)[surface_mask], ray_dirs[surface_mask])
+        elif self.training:
+            sdf_output = self.implicit_network(points)[:, 0:1]
             surface_mask = network_object_mask & object_mask
             surface_points = points[surface_mask]
             surface_dists = dists[surface_mask].unsqueeze(-1)
@@ -285,6 +332,7 @@ class IDRNetwork(nn.Module):
                                                                 surface_points_grad, surface_dists,
                                                                 surface_cam_loc, surface_ray_dirs)
         else:
+            sdf_output = self.implicit_network(points)[:, 0:1]
             surface_mask = network_object_mask
             differentiable_surface_points = points[surface_mask]
             grad_theta = None
@@ -304,8 +352,12 @@ class IDRNetwork(nn.Module):
         }
 
     def get_rbg_value(self, points, view_dirs):
-        output = self.implicit_network(points)
-        g = self.implicit_network.gradient(points)
+        if torch.is_grad_enabled():
+            output, g = self.implicit_network.forward_with_gradient(points)  # one evaluation instead of two
+        else:
+            output = self.implicit_network(points)
+            with torch.enable_grad():
+                g = self.implicit_network.gradient(points)
         normals = g[:, 0, :]
         feature_vectors = output[:, 1:]
         return self.rendering_network(points, normals, view_dirs, feature_vectors)

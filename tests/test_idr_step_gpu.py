@@ -38,10 +38,14 @@ def _close_mostly(a, b, rtol, atol, max_bad=0.005, what=""):
     assert bad.mean() <= max_bad, f"{what}: {bad.sum()} / {bad.size} outside tolerance, max {np.abs(a - b).max()}"
 
 
-def test_idr_training_steps(golden):
+@pytest.mark.parametrize("merge", [True, False])
+def test_idr_training_steps(golden, merge):
+    """merge=False runs the reference's exact evaluation structure (three SDF-network evaluations of the
+    ray points); merge=True the single merged evaluation - both must reproduce the reference run."""
     from hashmodnffbanks_idr_amd.model.loss import IDRLoss
     g = golden("idr_step_C1")
     model = _model(int(g["seed"]))
+    model.merge_evaluations = merge
     model.train()
     inp = {k: torch.from_numpy(g[k]).cuda() for k in ("intrinsics", "uv", "pose", "object_mask")}
     gt = {"rgb": torch.from_numpy(g["rgb_gt"]).cuda()}
