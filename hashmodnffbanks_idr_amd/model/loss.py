@@ -30,7 +30,9 @@ class IDRLoss(nn.Module):
             return torch.tensor(0.0, device=sdf_output.device).float()
         sdf_pred = -self.alpha * sdf_output[mask]
         gt = object_mask[mask].float()
-        bce = F.binary_cross_entropy_with_logits(sdf_pred.squeeze(), gt, reduction='sum')
+        # the reference squeezes ALL dims here (loss.py:46) and therefore raises when exactly one ray is
+        # in the mask set; reshape(-1) is the same tensor in every other case
+        bce = F.binary_cross_entropy_with_logits(sdf_pred.reshape(-1), gt, reduction='sum')
         return (1 / self.alpha) * bce / float(object_mask.shape[0])
 
     def forward(self, model_outputs, ground_truth):
