@@ -132,6 +132,35 @@ def gather_roofline(emb, log2_n=22, iters=10, warmup=3):
             "note": f"table {emb.table.numel() * 4 / 2**20:.1f} MiB is Infinity-Cache resident (<256 MiB)"}
 
 
+def gather_bwd_roofline(emb, log2_n=22, iters=10, warmup=3):
+    """Table-gradient scatter (hm_encode_bwd_table): 12 + L*F*4 + L*8*F*4*2 algorithmic bytes/point
+    (the RMW of all 8 corner rows is counted although zero-weight corners are skipped)."""
+    from hashmodnffbanks_idr_amd import ops
+    dev = emb.table.device
+    n = 1 << log2_n
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    x = (torch.rand((n, 3), generator=g) * 2 - 1).to(dev)
+    L, F = emb.n_levels, emb.n_features
+    d_feat = torch.randn((n, L * F), device=dev)
+    d_table = torch.zeros_like(emb.table)
+    for _ in range(warmup):
+        ops.encode_bwd_table(emb.desc, x, d_feat, 0, out=d_table)
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for s, e in evs:
+        s.record()
+        ops.encode_bwd_table(emb.desc, x, d_feat, 0, out=d_table)
+        e.record()
+    torch.cuda.synchronize()
+    ms = np.asarray([s.elapsed_time(e) for s, e in evs])
+    bpp = 12 + L * F * 4 + L * 8 * F * 4 * 2
+    avg_ms = float(ms.mean())
+    achieved = n * bpp / (avg_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "encode_bwd_table_kernel",
+            "units_per_launch": n, "bytes_per_unit": bpp, "avg_launch_ms": round(avg_ms, 4)}
+
+
 def mlp_roofline(net, log2_n=18, iters=5, warmup=2):
     """Fused SDF forward (encode + 9 MFMA layers), sdf-only output: 2*1 966 592 flop per point."""
     dev = next(net.parameters()).device
@@ -193,7 +222,24 @@ def main():
     ap.add_argument("--rays", type=int, default=RAYS_PER_GPU, help="rays per GPU")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / cpu_baseline sections")
     ap.add_argument("--gather-log2n", type=int, default=22)
+    ap.add_argument("--only", choices=["gather", "gather_bwd", "mlp"], default=None,
+                    help="profiling helper: run just one kernel section on cuda:0 and print its object")
+    ap.add_argument("--cfg", default=CFG, help="hash-grid config for --only sections (tests/golden/params.py)")
     args = ap.parse_args()
+
+    if args.only:
+        torch.manual_seed(0)
+        dev = torch.device("cuda", 0)
+        from hashmodnffbanks_idr_amd.model.implicit_differentiable_renderer import IDRNetwork
+        model = IDRNetwork(idr_conf(args.cfg)).to(dev)
+        emb = model.implicit_network.embed_model.embedder_obj
+        if args.only == "gather":
+            print(json.dumps(gather_roofline(emb, args.gather_log2n)))
+        elif args.only == "gather_bwd":
+            print(json.dumps(gather_bwd_roofline(emb, args.gather_log2n)))
+        else:
+            print(json.dumps(mlp_roofline(model.implicit_network)))
+        return
 
     from hashmodnffbanks_idr_amd import parallel
     from hashmodnffbanks_idr_amd.model.implicit_differentiable_renderer import IDRNetwork

@@ -9,15 +9,17 @@
 //
 // v_mfma_f32_32x32x2_f32 (exact fp32 fma chain); 4 waves per workgroup as 2 x 2, each owning
 // TM x TN tiles of 32 x 32; both operands are staged through LDS in the k-grouped image
-// [k/4][row][4] so that every MFMA operand fetch is a conflict-free ds_read_b128.
+// [k/4][row][4] (rows XOR-swizzled by the k-group) so that both the 16-B staging stores and the
+// MFMA operand fetches (ds_read_b128) are bank-conflict free; K is staged 64 deep for the 64x64
+// tile so that one stage of MFMAs (~0.85 us) covers the L2 latency of the next stage's loads.
 #include "hm_common.h"
+
+#include <stdlib.h>
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kBK = 16;  // k per stage = 4 k-groups = 2 MFMA octets
-constexpr int kGemmThreads = 256;
 
 struct GemmArgs {
     const float *A, *B, *bias;
@@ -27,58 +29,85 @@ struct GemmArgs {
     int64_t lda, ldb, ldc;
     int32_t k_chunk;  // K range handled by one blockIdx.z
     int32_t atomic;   // accumulate with atomics (split-K, or beta = 1)
+    int32_t vecA, vecB;  // operand may be fetched with aligned 16-B loads
 };
 
-// stage one operand tile: ROWS x kBK elements of op(X) into S[kgroup][row][4]
+// LDS image of an operand tile: S[kg][row][4] (kg = k/4) with the row XOR-swizzled by kg so that both
+// the 16-B staging stores (lanes = consecutive kg of one row) and the MFMA fragment loads (lanes =
+// consecutive rows of one kg) are bank-conflict free.
 template <int ROWS>
-__device__ __forceinline__ void load_tile(const float *__restrict__ P, int64_t ld, bool row_contig_k, int row0,
-                                          int nrows, int k0, int kend, int tid, float (&r)[ROWS * kBK / kGemmThreads]) {
-    constexpr int PER = ROWS * kBK / kGemmThreads;
+__device__ __forceinline__ int lds_slot(int kg, int row) {
+    return (kg * ROWS + (row ^ (kg & 7))) * 4;
+}
+
+// Fetch one ROWS x BK operand tile into registers as float4 k-groups.
+//   k-contiguous source (element (row,k) at P[row*ld + k]): lanes walk the k-groups of a row -> one
+//   coalesced 16-B load per k-group (VEC) or four dword loads;
+//   row-contiguous source (element (row,k) at P[k*ld + row]): lanes walk rows -> four coalesced dword
+//   loads (k, k+1, k+2, k+3) per k-group.
+// Every load is UNCONDITIONAL on a clamped in-range address and masked afterwards: a load under a
+// per-element branch makes hipcc wait vmcnt(0) per element and serialises the stage's L2 round trips.
+template <int ROWS, int BK, int NT, bool VEC>
+__device__ __forceinline__ void load_tile(const float *__restrict__ P, int64_t ld, bool kcontig, int row0,
+                                          int nrows, int k0, int kend, int tid, float4 (&r)[ROWS * BK / 4 / NT]) {
+    constexpr int PER = ROWS * BK / 4 / NT;
+    constexpr int KG = BK / 4;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-        const int e = tid + kGemmThreads * i;
-        int row, k;
-        if (row_contig_k) {  // element (row, k) at P[row*ld + k]
-            row = e / kBK;
-            k = e % kBK;
-        } else {  // element (row, k) at P[k*ld + row]
-            k = e / ROWS;
-            row = e % ROWS;
+        const int e = tid + NT * i;
+        const int row = kcontig ? e / KG : e % ROWS;
+        const int kg = kcontig ? e % KG : e / ROWS;
+        const int gr = row0 + row, gk = k0 + kg * 4;
+        const int rc = min(gr, nrows - 1);
+        const bool rv = gr < nrows;
+        float4 v;
+        if (VEC) {  // k-contiguous, kend % 4 == 0, 16-B aligned rows
+            const int kk = min(gk, kend - 4);
+            v = *reinterpret_cast<const float4 *>(P + (int64_t)rc * ld + kk);
+            const bool ok = rv && gk < kend;
+            v.x = ok ? v.x : 0.0f; v.y = ok ? v.y : 0.0f; v.z = ok ? v.z : 0.0f; v.w = ok ? v.w : 0.0f;
+        } else {
+            const int64_t sr = kcontig ? ld : 1, sk = kcontig ? 1 : ld;
+            const float *base = P + (int64_t)rc * sr;
+            const int c0 = min(gk, kend - 1), c1 = min(gk + 1, kend - 1), c2 = min(gk + 2, kend - 1),
+                      c3 = min(gk + 3, kend - 1);
+            const float x0 = base[(int64_t)c0 * sk], x1 = base[(int64_t)c1 * sk], x2 = base[(int64_t)c2 * sk],
+                        x3 = base[(int64_t)c3 * sk];
+            v.x = (rv && gk < kend) ? x0 : 0.0f;
+            v.y = (rv && gk + 1 < kend) ? x1 : 0.0f;
+            v.z = (rv && gk + 2 < kend) ? x2 : 0.0f;
+            v.w = (rv && gk + 3 < kend) ? x3 : 0.0f;
         }
-        const int gr = row0 + row, gk = k0 + k;
-        float v = 0.0f;
-        if (gr < nrows && gk < kend) v = row_contig_k ? P[(int64_t)gr * ld + gk] : P[(int64_t)gk * ld + gr];
         r[i] = v;
     }
 }
 
-template <int ROWS>
-__device__ __forceinline__ void store_tile(float *__restrict__ S, bool row_contig_k, int tid,
-                                           const float (&r)[ROWS * kBK / kGemmThreads]) {
-    constexpr int PER = ROWS * kBK / kGemmThreads;
+template <int ROWS, int BK, int NT>
+__device__ __forceinline__ void store_tile(float *__restrict__ S, bool kcontig, int tid,
+                                           const float4 (&r)[ROWS * BK / 4 / NT]) {
+    constexpr int PER = ROWS * BK / 4 / NT;
+    constexpr int KG = BK / 4;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-        const int e = tid + kGemmThreads * i;
-        int row, k;
-        if (row_contig_k) {
-            row = e / kBK;
-            k = e % kBK;
-        } else {
-            k = e / ROWS;
-            row = e % ROWS;
-        }
-        S[((k >> 2) * ROWS + row) * 4 + (k & 3)] = r[i];
+        const int e = tid + NT * i;
+        int row, kg;
+        if (kcontig) { row = e / KG; kg = e % KG; } else { kg = e / ROWS; row = e % ROWS; }
+        *reinterpret_cast<float4 *>(S + lds_slot<ROWS>(kg, row)) = r[i];
     }
 }
 
-template <int TM, int TN>
-__global__ __launch_bounds__(kGemmThreads) void gemm_f32_kernel(GemmArgs g) {
-    constexpr int BM = 64 * TM, BN = 64 * TN;
-    __shared__ __align__(16) float As[(kBK / 4) * BM * 4];
-    __shared__ __align__(16) float Bs[(kBK / 4) * BN * 4];
+// KS = intra-workgroup K split: 4*KS waves, wave group g multiplies octets [g*BK/8/KS, (g+1)*BK/8/KS) of every
+// stage, partial tiles are summed through LDS at the end.  Two waves per SIMD keep the matrix pipe busy
+// while the next stage's loads are in flight even when the grid has only one workgroup per CU.
+template <int TM, int TN, int BK, int KS, bool VA, bool VB>
+__global__ __launch_bounds__(256 * KS) void gemm_f32_kernel(GemmArgs g) {
+    constexpr int BM = 64 * TM, BN = 64 * TN, NT = 256 * KS;
+    __shared__ __align__(16) float As[BK * BM];
+    __shared__ __align__(16) float Bs[BK * BN];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int kpart = wave >> 2;
+    const int wm = (wave >> 1) & 1, wn = wave & 1;
     const int j = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int kbeg = blockIdx.z * g.k_chunk;
@@ -94,27 +123,29 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-    float ra[BM * kBK / kGemmThreads], rb[BN * kBK / kGemmThreads];
-    load_tile<BM>(g.A, g.lda, a_kc, m0, g.M, kbeg, kend, tid, ra);
-    load_tile<BN>(g.B, g.ldb, b_kc, n0, g.N, kbeg, kend, tid, rb);
-    for (int k0 = kbeg; k0 < kend; k0 += kBK) {
+    float4 ra[BM * BK / 4 / NT], rb[BN * BK / 4 / NT];
+    load_tile<BM, BK, NT, VA>(g.A, g.lda, a_kc, m0, g.M, kbeg, kend, tid, ra);
+    load_tile<BN, BK, NT, VB>(g.B, g.ldb, b_kc, n0, g.N, kbeg, kend, tid, rb);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
         __syncthreads();  // previous stage fully consumed
-        store_tile<BM>(As, a_kc, tid, ra);
-        store_tile<BN>(Bs, b_kc, tid, rb);
+        store_tile<BM, BK, NT>(As, a_kc, tid, ra);
+        store_tile<BN, BK, NT>(Bs, b_kc, tid, rb);
         __syncthreads();
-        if (k0 + kBK < kend) {  // prefetch the next stage into registers while this one is multiplied
-            load_tile<BM>(g.A, g.lda, a_kc, m0, g.M, k0 + kBK, kend, tid, ra);
-            load_tile<BN>(g.B, g.ldb, b_kc, n0, g.N, k0 + kBK, kend, tid, rb);
+        if (k0 + BK < kend) {  // prefetch the next stage into registers while this one is multiplied
+            load_tile<BM, BK, NT, VA>(g.A, g.lda, a_kc, m0, g.M, k0 + BK, kend, tid, ra);
+            load_tile<BN, BK, NT, VB>(g.B, g.ldb, b_kc, n0, g.N, k0 + BK, kend, tid, rb);
         }
+        constexpr int OCT = BK / 8 / KS;
 #pragma unroll
-        for (int o = 0; o < kBK / 8; ++o) {
+        for (int oo = 0; oo < OCT; ++oo) {
             float4 a[TM], b[TN];
+            const int kg = 2 * (kpart * OCT + oo) + h;
 #pragma unroll
             for (int t = 0; t < TM; ++t)
-                a[t] = *reinterpret_cast<const float4 *>(As + ((2 * o + h) * BM + wm * 32 * TM + t * 32 + j) * 4);
+                a[t] = *reinterpret_cast<const float4 *>(As + lds_slot<BM>(kg, wm * 32 * TM + t * 32 + j));
 #pragma unroll
             for (int t = 0; t < TN; ++t)
-                b[t] = *reinterpret_cast<const float4 *>(Bs + ((2 * o + h) * BN + wn * 32 * TN + t * 32 + j) * 4);
+                b[t] = *reinterpret_cast<const float4 *>(Bs + lds_slot<BN>(kg, wn * 32 * TN + t * 32 + j));
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -126,6 +157,23 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_kernel(GemmArgs g) {
                         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[tm][tn], 0, 0, 0);
                     }
         }
+    }
+
+    if (KS > 1) {
+        // sum the wave groups' partial tiles through LDS (the staging buffers are free now)
+        static_assert(KS == 1 || (TM == 1 && TN == 1), "intra-workgroup K split is built for the 64x64 tile");
+        __syncthreads();
+        float *red = As;  // (KS-1) * 4 waves * 16 regs * 64 lanes floats  <= BK*BM
+        if (kpart > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(((kpart - 1) * 4 + (wave & 3)) * 16 + r) * 64 + lane] = acc[0][0][r];
+        }
+        __syncthreads();
+        if (kpart > 0) return;
+#pragma unroll
+        for (int p = 0; p < KS - 1; ++p)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][0][r] += red[((p * 4 + (wave & 3)) * 16 + r) * 64 + lane];
     }
 
     // epilogue: lane holds column n, registers hold rows (r&3) + 8(r>>2) + 4h
@@ -171,10 +219,17 @@ int hm_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const f
     g.M = (int)M; g.N = (int)N; g.K = (int)K;
     g.transA = transA; g.transB = transB;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    // operands may be fetched with 16-B loads when every k-group of every row is 16-B aligned
+    const bool a_kc = !transA, b_kc = transB != 0;
+    // (and the K range ends on a multiple of 4, so no k-group straddles the end)
+    g.vecA = (a_kc && K % 4 == 0 && lda % 4 == 0 && (reinterpret_cast<uintptr_t>(A) & 15u) == 0) ? 1 : 0;
+    g.vecB = (b_kc && K % 4 == 0 && ldb % 4 == 0 && (reinterpret_cast<uintptr_t>(B) & 15u) == 0) ? 1 : 0;
     // tile choice: big tiles only when they still fill the chip
     const int64_t t128 = ((M + 127) / 128) * ((N + 127) / 128);
-    const bool big = t128 >= 192;
+    const bool big = t128 >= 256;
     const int64_t bm = big ? 128 : 64, bn = big ? 128 : 64;
+    static const int small_cfg = [] { const char *e = getenv("HM_GEMM_CFG"); return e ? atoi(e) : 0; }();
+    const int64_t kBK = big ? 32 : (small_cfg == 1 ? 64 : 128);
     const int64_t tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
     int64_t split = 1;
     if (tiles < 256 && K >= 256) {
@@ -197,10 +252,25 @@ int hm_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const f
     }
     dim3 grid((unsigned)((M + bm - 1) / bm), (unsigned)((N + bn - 1) / bn), (unsigned)split);
     HM_CHECK_ARG(grid.y <= 65535u && grid.z <= 65535u, "hm_gemm_f32: N or split too large for one launch");
+#define HM_GEMM_LAUNCH(TM_, TN_, BK_, KS_)                                                                      \
+    do {                                                                                                        \
+        if (g.vecA && g.vecB)                                                                                   \
+            hipLaunchKernelGGL((gemm_f32_kernel<TM_, TN_, BK_, KS_, true, true>), grid, dim3(256 * KS_), 0, st, g); \
+        else if (g.vecA)                                                                                        \
+            hipLaunchKernelGGL((gemm_f32_kernel<TM_, TN_, BK_, KS_, true, false>), grid, dim3(256 * KS_), 0, st, g); \
+        else if (g.vecB)                                                                                        \
+            hipLaunchKernelGGL((gemm_f32_kernel<TM_, TN_, BK_, KS_, false, true>), grid, dim3(256 * KS_), 0, st, g); \
+        else                                                                                                    \
+            hipLaunchKernelGGL((gemm_f32_kernel<TM_, TN_, BK_, KS_, false, false>), grid, dim3(256 * KS_), 0, st, g); \
+    } while (0)
+    hipStream_t st = as_stream(stream);
     if (big)
-        hipLaunchKernelGGL((gemm_f32_kernel<2, 2>), grid, dim3(kGemmThreads), 0, as_stream(stream), g);
+        HM_GEMM_LAUNCH(2, 2, 32, 1);
+    else if (small_cfg == 1)
+        HM_GEMM_LAUNCH(1, 1, 64, 1);
     else
-        hipLaunchKernelGGL((gemm_f32_kernel<1, 1>), grid, dim3(kGemmThreads), 0, as_stream(stream), g);
+        HM_GEMM_LAUNCH(1, 1, 128, 2);
+#undef HM_GEMM_LAUNCH
     HM_CHECK_LAUNCH("hm_gemm_f32");
     return HM_OK;
 }
