@@ -125,8 +125,16 @@ def gather_roofline(emb, log2_n=22, iters=10, warmup=3):
     bpp = gather_bytes_per_point(emb.n_levels, emb.n_features)
     avg_ms = float(ms.mean())
     achieved = n * bpp / (avg_ms * 1e-3) / 1e9
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "r01_gather_pmc.json")
+    if os.path.exists(pmc) and log2_n == 22 and emb.n_levels == 16:
+        # PMC counters cannot be read from inside this process: the number comes from the separate
+        # rocprofv3 --pmc passes of `bench.py --only gather` recorded under profiles/ (same kernel, same launch)
+        rec = json.load(open(pmc))
+        traffic, traffic_src = round(rec["traffic_bytes_per_launch_corrected"]), "profiles/r01_gather_pmc.json"
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "encode_fwd_f2_kernel",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": n * bpp, "kernel": "encode_fwd_f2_kernel",
             "units_per_launch": n, "bytes_per_unit": bpp, "avg_launch_ms": round(avg_ms, 4),
             "min_launch_ms": round(float(ms.min()), 4),
             "note": f"table {emb.table.numel() * 4 / 2**20:.1f} MiB is Infinity-Cache resident (<256 MiB)"}
