@@ -2,22 +2,21 @@
 constructor signature, registry keys, kwargs mapping and error behaviour
 (reference: code/model/custom_embedder_decoder.py:13-164).
 
-Registry coverage: 'HashGrid' (HIP kernels), 'FourierFeatures', 'NerfPos' (elementwise torch
-expressions, exactly the reference's).  'FFB' / 'StyleModNFFB' are the next tier (SURVEY.md
-section 8f); the tiny-cuda-nn variants ('HashGridTcnn', 'FFBTcnn') are out of scope by the north
-star ("not tiny-cuda-nn recompiled") and raise with a message that says so.
+Registry coverage: 'HashGrid', 'FFB', 'StyleModNFFB' (HIP hash-grid kernels + HIP GEMM),
+'FourierFeatures', 'NerfPos' (elementwise torch expressions, exactly the reference's).  The
+tiny-cuda-nn variants ('HashGridTcnn', 'FFBTcnn') are out of scope by the north star ("not
+tiny-cuda-nn recompiled") and raise with a message that says so.
 """
 import torch
 import torch.nn as nn
 
 from .embeddings.frequency_enc import FourierFeature, PositionalEncoding
 from .embeddings.hashGridEmbedding import MultiResHashGridMLP
+from .embeddings.nffb3d import FourierFilterBanks
 
 DEVICE = torch.device("cuda" if torch.cuda.is_available() else "cpu")
 
 _NOT_BUILT = {
-    'FFB': "Fourier filter banks (next tier, SURVEY.md 8f rank 1)",
-    'StyleModNFFB': "style-modulated NFFB (next tier, SURVEY.md 8f rank 1)",
     'HashGridTcnn': "tiny-cuda-nn backed encoder (excluded: no tcnn on MI355X)",
     'FFBTcnn': "tiny-cuda-nn backed encoder (excluded: no tcnn on MI355X)",
 }
@@ -43,6 +42,33 @@ class Custom_Embedding_Network(nn.Module):
                 'input_dims': input_dims,
                 'include_input': True,
             },
+            'fourier_filter_banks': {
+                'GridEncoderNetConfig': {
+                    'include_input': True, 'in_dim': input_dims, 'embed_type': 'HashGridTcnn',
+                    'network_dims': network_dims, 'n_levels': multires,
+                    'max_points_per_level': max_points_per_entry, 'log2_hashmap_size': log2_max_hash_size,
+                    'base_resolution': base_resolution, 'desired_resolution': desired_resolution,
+                    "base_sigma": 10.0, "exp_sigma": 1.26, "grid_embedding_std": 0.001, 'per_level_scale': 2.0,
+                },
+                'freq_enc_type': 'PositionalEncodingNET',
+                'has_out': False,
+                'bound': bound,
+                'layers_type': 'SIREN',
+            },
+            'StyleModulatedNFFB': {
+                'GridEncoderNetConfig': {
+                    'include_input': True, 'in_dim': input_dims, 'embed_type': 'HashGridTcnn',
+                    'network_dims': network_dims, 'n_levels': multires,
+                    'max_points_per_level': max_points_per_entry, 'log2_hashmap_size': log2_max_hash_size,
+                    'base_resolution': base_resolution, 'desired_resolution': desired_resolution,
+                    "base_sigma": 10.0, "exp_sigma": 1.26, "grid_embedding_std": 0.001, 'per_level_scale': 2.0,
+                },
+                'freq_enc_type': 'PositionalEncodingNET',
+                'has_out': False,
+                'bound': bound,
+                'layers_type': 'SIREN',
+                'style_modulation': True,
+            },
             'positional_encoding': {
                 'include_input': True,
                 'input_dims': input_dims,
@@ -54,6 +80,8 @@ class Custom_Embedding_Network(nn.Module):
         }
         embed_models = {
             'HashGrid': (MultiResHashGridMLP, 'hash_grid_encoder_pytorch'),
+            'FFB': (FourierFilterBanks, 'fourier_filter_banks'),
+            'StyleModNFFB': (FourierFilterBanks, 'StyleModulatedNFFB'),
             'NerfPos': (PositionalEncoding, 'positional_encoding'),
             'FourierFeatures': (FourierFeature, 'FourierFeature'),
         }

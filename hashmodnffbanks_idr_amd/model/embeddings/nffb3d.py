@@ -1,0 +1,94 @@
+"""FourierFilterBanks ('FFB') and its style-modulated variant ('StyleModNFFB') - BASELINE configs 3 and 5
+(reference: code/model/embeddings/nffb3d.py:24-194).
+
+Data flow (registry settings: PositionalEncodingNET, SIREN, has_out=False):
+  x_n = x / bound feeds a SIREN trunk  ff_lin0: 3 -> W, ff_lin1..L-2: W -> W,  W = 8 + 8L, sin(w0 .), w0 = L^F - L;
+  u = (x + bound) / (2 bound) feeds the hash grid; its output minus the 3 pass-through columns is cut into L
+  chunks of 2F values (this interleaves Fourier sin/cos and hash features exactly as the reference's
+  .view does), each chunk goes through a NeRF positional encoding -> [N, W];
+  after trunk layer l >= 1:  e = chunk_enc[l-1] (+ StyleAttention) + trunk ;  features += out_layer(e);
+  output = [u, features / L].
+The hash-grid gather runs on the HIP encoder kernels, every Linear on the HIP fp32 MFMA GEMM
+(ops.linear, differentiable to any order); sin/cos/normalisation are elementwise torch expressions.
+A fused narrow-MLP kernel for this trunk is the next optimisation step.
+"""
+import torch
+import torch.nn as nn
+
+from ... import ops
+from .frequency_enc import PositionalEncoding
+from .hashGridEmbedding import MultiResHashGridMLP
+from .Sine import Sine, first_layer_sine_init, sine_init
+from .style_Attention.styleMod import StyleAttention
+
+device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+
+
+class FourierFilterBanks(nn.Module):
+    def __init__(self, GridEncoderNetConfig, freq_enc_type, has_out, bound, layers_type, style_modulation=False):
+        super().__init__()
+        if freq_enc_type != 'PositionalEncodingNET' or layers_type != 'SIREN' or has_out:
+            raise NotImplementedError("FourierFilterBanks (HIP): only the registry's configuration is built "
+                                      "(PositionalEncodingNET, SIREN trunk, has_out=False)")
+        cfg = GridEncoderNetConfig
+        self.bound = bound
+        self.skip_in = [4]
+        self.include_input = cfg['include_input']
+        self.num_inputs = cfg['in_dim']
+        self.n_levels = cfg['n_levels']
+        self.max_points_per_level = cfg['max_points_per_level']
+        self.network_dims = cfg['network_dims']
+        self.modulationApplied = style_modulation
+        self.grid_levels = int(self.n_levels)
+        self.grid_enc = MultiResHashGridMLP(self.include_input, self.num_inputs, self.n_levels,
+                                            self.max_points_per_level, cfg['log2_hashmap_size'],
+                                            cfg['base_resolution'], cfg['desired_resolution']).to(device)
+        self.ff_enc = nn.Sequential(*[
+            PositionalEncoding(include_input=self.include_input, input_dims=self.max_points_per_level,
+                               max_freq_log2=self.n_levels - 1, num_freqs=self.n_levels, log_sampling=True,
+                               periodic_fns=[torch.sin, torch.cos]) for _ in range(self.grid_levels)])
+        width = 2 * self.ff_enc[-1].embeddings_dim
+        self.nffb_lin_dims = [self.num_inputs] + [width] * (self.grid_levels - 1)
+        self.n_nffb_layers = len(self.nffb_lin_dims)
+        assert self.n_nffb_layers >= 3, "The NFFB  should have more than 5 layers"
+        for layer in range(self.n_nffb_layers - 1):
+            setattr(self, "ff_lin" + str(layer), nn.Linear(self.nffb_lin_dims[layer], self.nffb_lin_dims[layer + 1]))
+        self.sin_w0 = self.n_levels ** self.max_points_per_level - self.n_levels
+        self.sin_w0_high = self.sin_w0 + 10
+        self.sin_activation = Sine(w0=self.sin_w0)
+        self.sin_activation_high = Sine(w0=self.sin_w0_high)
+        self.lin_activation = self.sin_activation
+        for layer in range(self.n_nffb_layers - 1):  # SIREN initialisation, same RNG order as the reference
+            lin = getattr(self, "ff_lin" + str(layer))
+            if layer == 0:
+                first_layer_sine_init(lin)
+            else:
+                sine_init(lin, self.sin_w0)
+        self.feature_Vector_size = width
+        self.has_out = has_out
+        self.embeddings_dim = width + self.num_inputs if self.include_input else width
+        self.out_layer = nn.Linear(width, width)
+        if self.modulationApplied:
+            self.StyleAttentionBlock = StyleAttention(self.num_inputs, self.feature_Vector_size)
+        for p in self.parameters():
+            p.requires_grad = True
+
+    def forward(self, input: torch.Tensor, compute_grad=False) -> torch.Tensor:
+        x = input / self.bound
+        u = (input + self.bound) / (2 * self.bound)
+        grid = self.grid_enc(u)[..., x.shape[-1]:]
+        chunks = grid.view(-1, self.grid_levels, 2 * self.max_points_per_level).permute(1, 0, 2)
+        # only chunks 0 .. L-3 are ever consumed (layers 1 .. L-2)
+        enc = [self.ff_enc[i](chunks[i]) for i in range(self.n_nffb_layers - 2)]
+        feats = None
+        for layer in range(self.n_nffb_layers - 1):
+            lin = getattr(self, 'ff_lin' + str(layer))
+            x = self.lin_activation(ops.linear(x, lin.weight, lin.bias))
+            if layer > 0:
+                e = enc[layer - 1]
+                if self.modulationApplied:
+                    e = self.StyleAttentionBlock(u, e)
+                e = e + x
+                f = ops.linear(e, self.out_layer.weight, self.out_layer.bias)
+                feats = f if feats is None else feats + f
+        return torch.cat([u, feats / self.grid_levels], dim=-1)

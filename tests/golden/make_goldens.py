@@ -414,7 +414,61 @@ def gen_camera():
          dirs44=d4.numpy(), cam44=c4.numpy(), R=Rm)
 
 
-GENS = dict(levels=gen_levels, hash_ids=gen_hash_ids, encode=gen_encode, encode_bwd=gen_encode_bwd,
+def gen_nffb():
+    """FourierFilterBanks ('FFB') and its style-modulated variant ('StyleModNFFB'): embedder outputs and
+    ImplicitNetwork forward / gradient / parameter-gradient norms with the reference's own (seeded) init."""
+    from model.custom_embedder_decoder import Custom_Embedding_Network
+    for tag, et in (("ffb", "FFB"), ("stylemod", "StyleModNFFB")):
+        for L in (6, 8):
+            torch.manual_seed(77)
+            emb = quiet(Custom_Embedding_Network, 3, [3, 512], et, L, 5, 2, 16, 512, 1.0)
+            sd = {k: v.clone() for k, v in emb.state_dict().items()}
+            # make the hash features matter
+            for k in sd:
+                if "embedding.weight" in k:
+                    sd[k] = torch.from_numpy(np.random.RandomState(5).uniform(-0.5, 0.5, tuple(sd[k].shape)).astype(np.float32))
+            emb.load_state_dict(sd)
+            x = P.make_points(300 + L, 256, -1.0, 1.0)
+            xt = T(x.copy()).requires_grad_(True)
+            y = emb(xt)
+            R = np.random.RandomState(9).standard_normal(tuple(y.shape)).astype(np.float32)
+            (y * T(R)).sum().backward()
+            arrays = dict(x=x, out=y.detach().numpy(), R=R, dx=xt.grad.numpy(), L=np.int64(L))
+            for k, v in sd.items():
+                arrays["sd:" + k] = v.numpy()
+            for k, p in emb.named_parameters():
+                arrays["gn:" + k] = np.float64(0.0 if p.grad is None else p.grad.double().norm().item())
+            save(f"nffb_{tag}_L{L}", **arrays)
+    # full SDF network on top of the FFB embedder (config 3 shape, narrow MLP to keep the fixture small)
+    for tag, et in (("ffb", "FFB"), ("stylemod", "StyleModNFFB")):
+        torch.manual_seed(78)
+        net = quiet(ImplicitNetwork, 16, 3, 1, [128] * 8, True, 0.6, [4], True, multires=6, embed_type=et,
+                    log2_max_hash_size=5, max_points_per_entry=2, base_resolution=16, desired_resolution=512, bound=1.0)
+        sd = {k: v.clone() for k, v in net.state_dict().items()}
+        rs = np.random.RandomState(6)
+        for k in sd:
+            if "embedding.weight" in k:
+                sd[k] = torch.from_numpy(rs.uniform(-0.5, 0.5, tuple(sd[k].shape)).astype(np.float32))
+        sd["lin0.weight_v"][:, 3:] = torch.from_numpy(rs.normal(0, 0.05, tuple(sd["lin0.weight_v"][:, 3:].shape)).astype(np.float32))
+        net.load_state_dict(sd)
+        x = P.make_points(400, 192, -1.0, 1.0)
+        net.eval()
+        with torch.no_grad():
+            out = net(T(x.copy())).numpy()
+        net.train()
+        g = net.gradient(T(x.copy()))
+        eik = ((g[:, 0, :].norm(2, dim=1) - 1) ** 2).mean()
+        net.zero_grad()
+        eik.backward()
+        arrays = dict(x=x, out=out, gradient=g.detach().numpy()[:, 0], eik=np.float64(eik.item()))
+        for k, v in sd.items():
+            arrays["sd:" + k] = v.numpy()
+        for k, p in net.named_parameters():
+            arrays["g2n:" + k] = np.float64(-1.0 if p.grad is None else p.grad.double().norm().item())
+        save(f"nffb_sdf_{tag}", **arrays)
+
+
+GENS = dict(nffb=gen_nffb, levels=gen_levels, hash_ids=gen_hash_ids, encode=gen_encode, encode_bwd=gen_encode_bwd,
             sdf=gen_sdf, raytrace=gen_raytrace, idr_step=gen_idr_step, init_rng=gen_init_rng,
             camera=gen_camera)
 

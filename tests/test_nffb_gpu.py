@@ -1,0 +1,71 @@
+"""FourierFilterBanks ('FFB') / StyleModNFFB embedders (BASELINE configs 3 and 5) against reference fixtures."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _load(mod, g, prefix="sd:"):
+    sd = {k[len(prefix):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(prefix)}
+    mod.load_state_dict(sd)
+    return mod.cuda()
+
+
+@pytest.mark.parametrize("tag,et", [("ffb", "FFB"), ("stylemod", "StyleModNFFB")])
+@pytest.mark.parametrize("L", [6, 8])
+def test_embedder_forward_backward(golden, tag, et, L):
+    from hashmodnffbanks_idr_amd.model.custom_embedder_decoder import Custom_Embedding_Network
+    g = golden(f"nffb_{tag}_L{L}")
+    emb = _load(Custom_Embedding_Network(3, [3, 512], et, L, 5, 2, 16, 512, 1.0), g)
+    assert emb.embeddings_dim == 3 + 8 + 8 * L
+    x = torch.from_numpy(g["x"].copy()).cuda().requires_grad_(True)
+    y = emb(x)
+    # sin(w0 * .) with w0 = 30 / 56 amplifies last-bit differences of the trunk pre-activations
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g["out"], rtol=1e-4, atol=2e-5)
+    (y * torch.from_numpy(g["R"]).cuda()).sum().backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g["dx"], rtol=1e-3, atol=1e-3 * np.abs(g["dx"]).max())
+    eo = emb.embedder_obj.grid_enc
+    off = eo.desc.row_off
+    for k, p in emb.named_parameters():
+        if k.endswith("grid_enc.table"):
+            for l in range(L):
+                ref = float(g[f"gn:embedder_obj.grid_enc.levels.{l}.embedding.weight"])
+                got = p.grad[int(off[l]):int(off[l + 1])].double().norm().item()
+                assert abs(got - ref) <= 1e-3 * ref + 1e-7, (k, l, got, ref)
+        else:
+            ref = float(g["gn:" + k])
+            got = 0.0 if p.grad is None else p.grad.double().norm().item()
+            assert abs(got - ref) <= 1e-3 * ref + 1e-6, (k, got, ref)
+
+
+@pytest.mark.parametrize("tag,et", [("ffb", "FFB"), ("stylemod", "StyleModNFFB")])
+def test_sdf_network_on_nffb(golden, tag, et):
+    from hashmodnffbanks_idr_amd.model.implicit_differentiable_renderer import ImplicitNetwork
+    g = golden(f"nffb_sdf_{tag}")
+    net = ImplicitNetwork(16, 3, 1, [128] * 8, True, 0.6, [4], True, multires=6, embed_type=et, log2_max_hash_size=5,
+                          max_points_per_entry=2, base_resolution=16, desired_resolution=512, bound=1.0)
+    net = _load(net, g)
+    x = torch.from_numpy(g["x"].copy()).cuda()
+    net.eval()
+    with torch.no_grad():
+        out = net(x)
+        sdf = net.sdf(x)
+    np.testing.assert_allclose(out.cpu().numpy(), g["out"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(sdf.cpu().numpy(), g["out"][:, 0], rtol=1e-4, atol=2e-5)
+    net.train()
+    gr = net.gradient(torch.from_numpy(g["x"].copy()).cuda())
+    np.testing.assert_allclose(gr.detach().cpu().numpy()[:, 0], g["gradient"], rtol=1e-3,
+                               atol=1e-3 * np.abs(g["gradient"]).max())
+    eik = ((gr[:, 0, :].norm(2, dim=1) - 1) ** 2).mean()
+    assert abs(eik.item() - float(g["eik"])) <= 1e-3 * float(g["eik"])
+    eik.backward()
+    for k, p in net.named_parameters():
+        if k.endswith("table"):
+            continue
+        ref = float(g["g2n:" + k])
+        if ref < 0:
+            assert p.grad is None
+            continue
+        got = p.grad.double().norm().item()
+        assert abs(got - ref) <= 5e-3 * ref + 1e-6, (k, got, ref)
