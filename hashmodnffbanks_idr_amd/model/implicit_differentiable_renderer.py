@@ -127,10 +127,18 @@ class ImplicitNetwork(nn.Module):
             with torch.no_grad():
                 Ws = [_folded_weight(getattr(self, "lin" + str(l))) for l in range(self.num_layers - 1)]
                 bs = [getattr(self, "lin" + str(l)).bias for l in range(self.num_layers - 1)]
-                beta = float(self.dencity_net.get_beta())
-                self._packed = ops.PackedSdf(Ws, bs, self.dims[0], self.skip_in, beta)
+                self._packed = ops.PackedSdf(Ws, bs, self.dims[0], self.skip_in, self._beta_value())
             self._packed_key = key
         return self._packed
+
+    def _beta_value(self):
+        """|beta| + beta_min as a Python float; read back from the device only when the parameter changed
+        (it never receives a gradient), so re-packing inside a captured graph does not synchronise."""
+        b = self.dencity_net.beta
+        key = (b.data_ptr(), b._version)
+        if getattr(self, "_beta_cache", (None, None))[0] != key:
+            self._beta_cache = (key, float(self.dencity_net.get_beta()))
+        return self._beta_cache[1]
 
     def _fused(self, x, sdf_only):
         emb = self._hash_embedder()
@@ -350,6 +358,67 @@ class IDRNetwork(nn.Module):
             'object_mask': object_mask,
             'grad_theta': grad_theta,
         }
+
+    def forward_static(self, input, eikonal_points, steps_u=None):
+        """Training forward with STATIC shapes and no host synchronisation (fixed cameras only):
+        the same quantities as forward(), but every per-ray selection is a mask instead of a
+        boolean gather, so the step can be captured in a HIP graph (training/graph_step.py).
+
+        Differences in mechanism: the rendering branch is evaluated for all rays and masked (the
+        reference gathers the surface rays first); SampleNetwork's denominator is replaced by 1 on
+        non-surface rays (their numerator is exactly 0, so the point is unchanged and finite).
+        eikonal_points [n_rays//2, 3] and steps_u [n_steps] are the two random draws the reference
+        makes inside forward (:277, ray_tracing.py:277), passed in as device tensors."""
+        cache = {}
+        self.implicit_network._fold_cache = cache
+        self.rendering_network._fold_cache = cache
+        try:
+            uv, pose, intrinsics = input["uv"], input["pose"], input["intrinsics"]
+            object_mask = input["object_mask"].reshape(-1)
+            ray_dirs, cam_loc = rend_util.get_camera_params(uv, pose, intrinsics)
+            if ray_dirs.requires_grad or cam_loc.requires_grad:
+                raise RuntimeError("forward_static needs fixed cameras (pose without gradient)")
+            batch_size, num_pixels, _ = ray_dirs.shape
+            n_rays = batch_size * num_pixels
+            self.implicit_network.eval()
+            old = self.ray_tracer.steps_override
+            self.ray_tracer.steps_override = steps_u
+            try:
+                with torch.no_grad():
+                    _, network_object_mask, dists = self.ray_tracer(
+                        sdf=self.implicit_network.sdf, cam_loc=cam_loc, object_mask=object_mask,
+                        ray_directions=ray_dirs)
+            finally:
+                self.ray_tracer.steps_override = old
+            self.implicit_network.train()
+            points = (cam_loc.unsqueeze(1) + dists.reshape(batch_size, num_pixels, 1) * ray_dirs).reshape(-1, 3)
+            ray_dirs = ray_dirs.reshape(-1, 3)
+            cams = cam_loc.unsqueeze(1).repeat(1, num_pixels, 1).reshape(-1, 3)
+
+            x_all = torch.cat([points.detach(), eikonal_points], 0)
+            out_all, g_all = self.implicit_network.forward_with_gradient(x_all)
+            sdf_output = out_all[:n_rays, 0:1]
+            surface_mask = network_object_mask & object_mask
+            m = surface_mask.unsqueeze(-1)
+            grad_theta = torch.cat([g_all[n_rays:, 0, :], g_all[:n_rays, 0, :]], 0)
+
+            # SampleNetwork (sample_network.py:10-20) on every ray; denominators of non-surface rays -> 1
+            grad0 = g_all[:n_rays, 0, :].detach()
+            dot = (grad0 * ray_dirs).sum(-1, keepdim=True)
+            dot = torch.where(m, dot, torch.ones_like(dot))
+            t_theta = dists.unsqueeze(-1) - (sdf_output - sdf_output.detach()) / dot
+            diff_points = cams + t_theta * ray_dirs
+
+            out2, g2 = self.implicit_network.forward_with_gradient(diff_points)
+            rgb = self.rendering_network(diff_points, g2[:, 0, :], -ray_dirs, out2[:, 1:])
+            rgb_values = torch.where(m, rgb, torch.ones_like(rgb))
+            return {
+                'points': points, 'rgb_values': rgb_values, 'sdf_output': sdf_output,
+                'network_object_mask': network_object_mask, 'object_mask': object_mask, 'grad_theta': grad_theta,
+            }
+        finally:
+            self.implicit_network._fold_cache = None
+            self.rendering_network._fold_cache = None
 
     def get_rbg_value(self, points, view_dirs):
         if torch.is_grad_enabled():

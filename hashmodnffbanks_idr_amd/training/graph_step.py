@@ -1,0 +1,107 @@
+"""One training iteration as a captured HIP graph (the MI355X answer to the reference runner's
+~2000 eager launches and >= 12 host synchronisations per iteration, training/idr_train.py:278-321).
+
+The iteration keeps the reference's order - forward, IDRLoss, backward, [gradient all-reduce],
+clip_grad_norm_(1.0), dense Adam - but runs the static-shape forward (IDRNetwork.forward_static:
+masks instead of boolean gathers, the whole ray search enqueued by one C call) so that nothing
+depends on a device->host read.  The first calls run eagerly (warm-up on a side stream), then the
+kernels of [forward + loss + backward] and of [clip + Adam] are captured once with
+torch.cuda.CUDAGraph (hipGraph underneath) and replayed; only the two CPU-generator draws the reference
+makes per iteration (eikonal samples, closest-approach fractions) are copied in before each replay.
+With more than one rank the RCCL all-reduce runs eagerly between the two graphs.
+"""
+import torch
+import torch.nn.functional as F
+
+
+def idr_loss_static(out, rgb_gt, eikonal_weight, mask_weight, alpha):
+    """IDRLoss (reference model/loss.py:4-70) with masks instead of boolean gathers: identical terms,
+    no `.sum() == 0` host checks (an empty selection contributes an exact 0)."""
+    net, obj = out['network_object_mask'], out['object_mask']
+    n = float(obj.shape[0])
+    sel = (net & obj).unsqueeze(-1)
+    rgb_loss = (torch.abs(out['rgb_values'] - rgb_gt.reshape(-1, 3)) * sel).sum() / n
+    g = out['grad_theta']
+    eikonal_loss = ((g.norm(2, dim=1) - 1) ** 2).mean()
+    msel = ~(net & obj)
+    logits = (-alpha * out['sdf_output']).reshape(-1)
+    bce = F.binary_cross_entropy_with_logits(logits, obj.float(), reduction='none')
+    mask_loss = (1 / alpha) * (bce * msel).sum() / n
+    loss = rgb_loss + eikonal_weight * eikonal_loss + mask_weight * mask_loss
+    return {'loss': loss, 'rgb_loss': rgb_loss, 'eikonal_loss': eikonal_loss, 'mask_loss': mask_loss}
+
+
+class GraphedTrainStep:
+    def __init__(self, model, loss_fn, optimizer, reducer=None, max_norm=1.0, warmup=3, use_graph=True):
+        self.model, self.loss_fn, self.opt, self.reducer = model, loss_fn, optimizer, reducer
+        self.max_norm, self.warmup_left, self.use_graph = max_norm, warmup, use_graph
+        self.g_fb = self.g_opt = None
+        self.static = None
+        self.out = self.loss_out = None
+        for grp in optimizer.param_groups:
+            if use_graph and not grp.get("capturable", False):
+                raise ValueError("GraphedTrainStep needs torch.optim.Adam(..., capturable=True)")
+
+    # -- pieces -------------------------------------------------------------------------------
+    def _draws(self, n_rays, dev):
+        """the reference's two CPU-generator draws of an iteration, in its order (ray_tracing.py:277 first,
+        then implicit_differentiable_renderer.py:279)"""
+        rt = self.model.ray_tracer
+        steps = torch.empty(rt.n_steps).uniform_(0.0, 1.0)
+        bb = self.model.object_bounding_sphere
+        eik = torch.empty(n_rays // 2, 3).uniform_(-bb, bb)
+        return steps, eik
+
+    def _fwd_bwd(self):
+        s = self.static
+        out = self.model.forward_static(s["input"], s["eik"], s["steps"])
+        lo = idr_loss_static(out, s["rgb"], self.loss_fn.eikonal_weight, self.loss_fn.mask_weight, self.loss_fn.alpha)
+        lo["loss"].backward()
+        return out, lo
+
+    def _update(self):
+        torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=self.max_norm)
+        self.opt.step()
+
+    # -- driver -------------------------------------------------------------------------------
+    def step(self, model_input, ground_truth):
+        dev = model_input["uv"].device
+        n_rays = model_input["uv"].shape[0] * model_input["uv"].shape[1]
+        steps, eik = self._draws(n_rays, dev)
+        if self.static is None:
+            self.static = {"input": {k: v.clone() for k, v in model_input.items()},
+                           "rgb": ground_truth["rgb"].to(dev).clone(), "eik": eik.to(dev), "steps": steps.to(dev)}
+        else:
+            s = self.static
+            for k, v in model_input.items():
+                s["input"][k].copy_(v, non_blocking=True)
+            s["rgb"].copy_(ground_truth["rgb"], non_blocking=True)
+            s["eik"].copy_(eik, non_blocking=True)
+            s["steps"].copy_(steps, non_blocking=True)
+
+        if not self.use_graph or self.warmup_left > 0:
+            self.warmup_left -= 1
+            self.opt.zero_grad(set_to_none=True)
+            self.out, self.loss_out = self._fwd_bwd()
+            if self.reducer is not None:
+                self.reducer()
+            self._update()
+            return self.out, self.loss_out
+
+        if self.g_fb is None:
+            # capture (records the kernels, does not run them), then fall through to the first replay
+            self.model.implicit_network._packed = None  # make the capture contain the weight re-pack
+            self.opt.zero_grad(set_to_none=True)
+            torch.cuda.synchronize()
+            self.g_fb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_fb):
+                self.out, self.loss_out = self._fwd_bwd()
+            self.g_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_opt):
+                self._update()
+
+        self.g_fb.replay()
+        if self.reducer is not None:
+            self.reducer()
+        self.g_opt.replay()
+        return self.out, self.loss_out

@@ -61,16 +61,17 @@ def get_camera_params(uv, pose, intrinsics):
 
 def get_sphere_intersection(cam_loc, ray_directions, r=1.0):
     """near/far ray parameters of the bounding sphere |p| = r, clamped at 0, and the hit mask
-    (rend_util.py:141-162).  cam_loc [B,3], ray_directions [B,N,3] -> [B,N,2], [B,N]."""
+    (rend_util.py:141-162).  cam_loc [B,3], ray_directions [B,N,3] -> [B,N,2], [B,N].
+    Written with torch.where instead of the reference's boolean-mask assignment: same values, static
+    shapes, no device->host synchronisation (so it can sit inside a captured HIP graph)."""
     n_imgs, n_pix, _ = ray_directions.shape
-    dev = ray_directions.device
     c = cam_loc.unsqueeze(-1)
-    ray_cam_dot = torch.bmm(ray_directions, c).squeeze()
-    under_sqrt = (ray_cam_dot ** 2 - (c.norm(2, 1) ** 2 - r ** 2)).reshape(-1)
+    ray_cam_dot = torch.bmm(ray_directions, c).reshape(-1)
+    under_sqrt = (ray_cam_dot ** 2 - (c.norm(2, 1) ** 2 - r ** 2).repeat_interleave(n_pix, 0).reshape(-1))
     mask_intersect = under_sqrt > 0
-    t = torch.zeros(n_imgs * n_pix, 2, device=dev, dtype=torch.float32)
-    signs = torch.tensor([-1.0, 1.0], device=dev)
-    t[mask_intersect] = torch.sqrt(under_sqrt[mask_intersect]).unsqueeze(-1) * signs
-    t[mask_intersect] -= ray_cam_dot.reshape(-1)[mask_intersect].unsqueeze(-1)
+    root = torch.sqrt(torch.where(mask_intersect, under_sqrt, torch.ones_like(under_sqrt)))
+    signs = torch.tensor([-1.0, 1.0], device=ray_directions.device)
+    t = root.unsqueeze(-1) * signs - ray_cam_dot.unsqueeze(-1)
+    t = torch.where(mask_intersect.unsqueeze(-1), t, torch.zeros_like(t))
     t = t.reshape(n_imgs, n_pix, 2).clamp_min(0.0)
     return t, mask_intersect.reshape(n_imgs, n_pix)

@@ -1,0 +1,78 @@
+"""Static-shape forward / graph-captured training step against the dynamic (reference-structured) step."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+import bench
+from helpers import idr_conf
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(seed=3):
+    from hashmodnffbanks_idr_amd.model.implicit_differentiable_renderer import IDRNetwork
+    from hashmodnffbanks_idr_amd.model.loss import IDRLoss
+    torch.manual_seed(seed)
+    model = IDRNetwork(idr_conf("C1")).cuda()
+    with torch.no_grad():  # let the hash features matter
+        model.implicit_network.lin0.weight_v[:, 3:].normal_(0, 0.02)
+        model.implicit_network.embed_model.embedder_obj.table.uniform_(-0.05, 0.05)
+    model.train()
+    inp, gt = bench.synthetic_batch(21, 512, "cuda")
+    rs = np.random.RandomState(4)
+    inp["object_mask"] = torch.from_numpy(rs.uniform(0, 1, (1, 512)) < 0.8).cuda()
+    gt["rgb"] = torch.from_numpy(rs.uniform(-1, 1, (1, 512, 3)).astype(np.float32)).cuda()
+    return model, IDRLoss(eikonal_weight=0.1, mask_weight=100.0, alpha=50.0), inp, gt
+
+
+def test_static_forward_matches_dynamic_forward():
+    from hashmodnffbanks_idr_amd.training.graph_step import idr_loss_static
+    model, loss_fn, inp, gt = _setup()
+    torch.manual_seed(5)
+    out_d = model(inp)
+    lo_d = loss_fn(out_d, gt)
+    model.zero_grad()
+    lo_d["loss"].backward()
+    gd = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    torch.manual_seed(5)
+    steps = torch.empty(100).uniform_(0.0, 1.0).cuda()
+    eik = torch.empty(256, 3).uniform_(-1.0, 1.0).cuda()
+    out_s = model.forward_static(inp, eik, steps)
+    lo_s = idr_loss_static(out_s, gt["rgb"], 0.1, 100.0, 50.0)
+    model.zero_grad()
+    lo_s["loss"].backward()
+    assert torch.equal(out_s["network_object_mask"], out_d["network_object_mask"])
+    for k in ("loss", "rgb_loss", "eikonal_loss", "mask_loss"):
+        assert abs(lo_s[k].item() - lo_d[k].item()) <= 1e-5 * abs(lo_d[k].item()) + 1e-7, k
+    np.testing.assert_allclose(out_s["rgb_values"].detach().cpu(), out_d["rgb_values"].detach().cpu(), rtol=1e-4, atol=1e-5)
+    for n, p in model.named_parameters():
+        if n in gd:
+            a, b = p.grad, gd[n]
+            scale = b.abs().max().item() + 1e-12
+            assert (a - b).abs().max().item() <= 2e-4 * scale, (n, (a - b).abs().max().item(), scale)
+
+
+def test_graphed_step_matches_eager_static_step():
+    from hashmodnffbanks_idr_amd.training.graph_step import GraphedTrainStep
+    model_a, loss_fn, inp, gt = _setup()
+    model_b = copy.deepcopy(model_a)
+    runs = []
+    for model, use_graph in ((model_a, True), (model_b, False)):
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, capturable=True)
+        stepper = GraphedTrainStep(model, loss_fn, opt, warmup=2, use_graph=use_graph)
+        torch.manual_seed(9)
+        losses = []
+        for _ in range(6):
+            out, lo = stepper.step(inp, gt)
+            losses.append(lo["loss"].item())
+        runs.append((losses, {n: p.detach().clone() for n, p in model.named_parameters()},
+                     model.ray_tracer.last_stats))
+    (la, pa, sa), (lb, pb, sb) = runs
+    assert sa["unfinished"] == 0 and sb["unfinished"] == 0
+    for x, y in zip(la, lb):
+        assert abs(x - y) <= 2e-3 * abs(y) + 1e-6, (la, lb)
+    for n in pa:
+        assert (pa[n] - pb[n]).abs().max().item() <= 5e-4, n
