@@ -99,6 +99,11 @@ class ImplicitNetwork(nn.Module):
         self._fold_cache = None
         self.sdf_tile_points = 0  # fused kernel tile: 0 auto (16-point tiles for small batches), 16, 64
 
+    def __getstate__(self):  # the packed-weight cache holds raw device pointers: never copied / pickled
+        d = self.__dict__.copy()
+        d["_packed"], d["_packed_key"], d["_fold_cache"] = None, None, None
+        return d
+
     # ---- fused no-grad path ---------------------------------------------------------------
     def _hash_embedder(self):
         emb = getattr(self, "embed_model", None)

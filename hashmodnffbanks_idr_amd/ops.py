@@ -47,6 +47,9 @@ class GridDesc:
     def handle(self):
         return self._h
 
+    def __reduce__(self):  # copy.deepcopy / pickle: rebuild the native descriptor from the host arrays
+        return (GridDesc, (self.res.tolist(), self.rows.tolist(), self.F))
+
     def __del__(self):
         try:
             if self._h:
