@@ -58,7 +58,8 @@ def test_static_forward_matches_dynamic_forward():
 def test_graphed_step_matches_eager_static_step():
     from hashmodnffbanks_idr_amd.training.graph_step import GraphedTrainStep
     model_a, loss_fn, inp, gt = _setup()
-    model_b = copy.deepcopy(model_a)
+    model_b = _setup()[0]  # (nn.utils.weight_norm modules cannot be deep-copied)
+    model_b.load_state_dict(model_a.state_dict())
     runs = []
     for model, use_graph in ((model_a, True), (model_b, False)):
         opt = torch.optim.Adam(model.parameters(), lr=1e-4, capturable=True)
