@@ -70,8 +70,7 @@ def get_sphere_intersection(cam_loc, ray_directions, r=1.0):
     under_sqrt = (ray_cam_dot ** 2 - (c.norm(2, 1) ** 2 - r ** 2).repeat_interleave(n_pix, 0).reshape(-1))
     mask_intersect = under_sqrt > 0
     root = torch.sqrt(torch.where(mask_intersect, under_sqrt, torch.ones_like(under_sqrt)))
-    signs = torch.tensor([-1.0, 1.0], device=ray_directions.device)
-    t = root.unsqueeze(-1) * signs - ray_cam_dot.unsqueeze(-1)
+    t = torch.stack([root * -1.0, root], -1) - ray_cam_dot.unsqueeze(-1)   # sqrt * [-1, 1] - <d, c>
     t = torch.where(mask_intersect.unsqueeze(-1), t, torch.zeros_like(t))
     t = t.reshape(n_imgs, n_pix, 2).clamp_min(0.0)
     return t, mask_intersect.reshape(n_imgs, n_pix)
