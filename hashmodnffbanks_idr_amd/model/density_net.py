@@ -21,15 +21,16 @@ class LaplaceDensity(Density):
     def __init__(self, params_init={}, beta_min=0.0001):
         super().__init__(params_init=params_init)
         self.beta_min = torch.tensor(beta_min)
+        self._beta_min = float(beta_min)  # added as a scalar: no host->device copy per call (graph capturable)
 
     @torch.no_grad()
     def density_func(self, sdf, beta=None):
         if beta is None:
             beta = self.get_beta()
         else:
-            beta = torch.tensor(self.beta_min + self.beta.abs())
+            beta = self.beta.abs() + self._beta_min
         alpha = 1 / beta
         return alpha * (0.5 + 0.5 * sdf.sign() * torch.expm1(-sdf.abs() / beta))
 
     def get_beta(self):
-        return self.beta.abs() + self.beta_min.to(self.beta.device)
+        return self.beta.abs() + self._beta_min
