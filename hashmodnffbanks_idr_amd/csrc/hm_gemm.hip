@@ -199,6 +199,15 @@ __global__ __launch_bounds__(256 * KS) void gemm_f32_kernel(GemmArgs g) {
         }
 }
 
+// zero an M x N window of C (split-K accumulates with atomics); a plain kernel instead of
+// hipMemset2DAsync so that the call can be recorded into a HIP graph on every ROCm version
+__global__ __launch_bounds__(256) void zero_window_kernel(float *C, int64_t ldc, int64_t M, int64_t N) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * N) return;
+    const int64_t m = i / N, n = i - m * N;
+    C[m * ldc + n] = 0.0f;
+}
+
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 }  // namespace
@@ -246,9 +255,8 @@ int hm_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const f
     g.atomic = (accumulate || split > 1) ? 1 : 0;
     if (split > 1 && !accumulate) {
         // split-K accumulates with atomics into a zeroed C
-        hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M,
-                                        as_stream(stream));
-        if (e != hipSuccess) return hm_fail(HM_ERR_HIP, std::string("hipMemset2DAsync: ") + hipGetErrorString(e));
+        hipLaunchKernelGGL(zero_window_kernel, dim3((unsigned)((M * N + 255) / 256)), dim3(256), 0, as_stream(stream),
+                           C, ldc, M, N);
     }
     dim3 grid((unsigned)((M + bm - 1) / bm), (unsigned)((N + bn - 1) / bn), (unsigned)split);
     HM_CHECK_ARG(grid.y <= 65535u && grid.z <= 65535u, "hm_gemm_f32: N or split too large for one launch");
