@@ -36,6 +36,7 @@ class GraphedTrainStep:
         self.model, self.loss_fn, self.opt, self.reducer = model, loss_fn, optimizer, reducer
         self.max_norm, self.warmup_left, self.use_graph = max_norm, warmup, use_graph
         self.g_fb = self.g_opt = None
+        self.side = None
         self.static = None
         self.out = self.loss_out = None
         for grp in optimizer.param_groups:
@@ -63,6 +64,13 @@ class GraphedTrainStep:
         torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=self.max_norm)
         self.opt.step()
 
+    def _eager_iteration(self):
+        self.opt.zero_grad(set_to_none=True)
+        self.out, self.loss_out = self._fwd_bwd()
+        if self.reducer is not None:
+            self.reducer()
+        self._update()
+
     # -- driver -------------------------------------------------------------------------------
     def step(self, model_input, ground_truth):
         dev = model_input["uv"].device
@@ -81,11 +89,18 @@ class GraphedTrainStep:
 
         if not self.use_graph or self.warmup_left > 0:
             self.warmup_left -= 1
-            self.opt.zero_grad(set_to_none=True)
-            self.out, self.loss_out = self._fwd_bwd()
-            if self.reducer is not None:
-                self.reducer()
-            self._update()
+            if self.use_graph:
+                # warm-up iterations must run on a side stream before capture (autograd's backward
+                # thread and the library workspaces otherwise stay bound to the legacy stream and
+                # hipStreamEndCapture crashes)
+                if self.side is None:
+                    self.side = torch.cuda.Stream()
+                self.side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self.side):
+                    self._eager_iteration()
+                torch.cuda.current_stream().wait_stream(self.side)
+            else:
+                self._eager_iteration()
             return self.out, self.loss_out
 
         if self.g_fb is None:
