@@ -229,6 +229,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rays", type=int, default=RAYS_PER_GPU, help="rays per GPU")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / cpu_baseline sections")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="eager reference-structured step (dynamic shapes) instead of the HIP-graph captured step")
     ap.add_argument("--gather-log2n", type=int, default=22)
     ap.add_argument("--only", choices=["gather", "gather_bwd", "mlp"], default=None,
                     help="profiling helper: run just one kernel section on cuda:0 and print its object")
@@ -263,10 +265,21 @@ def main():
     model = IDRNetwork(idr_conf(CFG)).to(device)
     model.train()
     loss_fn = IDRLoss(eikonal_weight=0.1, mask_weight=100.0, alpha=50.0)
-    opt = torch.optim.Adam(model.parameters(), lr=1.0e-4)
+    opt = torch.optim.Adam(model.parameters(), lr=1.0e-4, capturable=not args.no_graph)
     reducer = parallel.GradAllReducer(model.parameters()) if world > 1 else None
     inp, gt = synthetic_batch(1234 + rank, args.rays, device)
     torch.manual_seed(100 + rank)  # per-rank eikonal points / step fractions
+    if args.no_graph:
+        def run_step():
+            return parallel.train_step(model, loss_fn, opt, inp, gt, reducer)
+    else:
+        from hashmodnffbanks_idr_amd.training.graph_step import GraphedTrainStep
+        stepper = GraphedTrainStep(model, loss_fn, opt, reducer, warmup=2)
+
+        def run_step():
+            return stepper.step(inp, gt)
+        for _ in range(max(0, 3 - args.warmup)):  # the capture must not fall into the timed region
+            run_step()
 
     def barrier():
         if world > 1:
@@ -274,11 +287,11 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        parallel.train_step(model, loss_fn, opt, inp, gt, reducer)
+        run_step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        _, lo = parallel.train_step(model, loss_fn, opt, inp, gt, reducer)
+        _, lo = run_step()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -297,6 +310,8 @@ def main():
                                    "(BASELINE.json configs[1]), full IDR training step",
                        "rays_per_gpu": args.rays, "global_rays": args.rays * world,
                        "parallelism": f"ray-sharded dp{world}" if world > 1 else "single GPU",
+                       "step": "eager (reference-structured, dynamic shapes)" if args.no_graph
+                       else "HIP-graph captured static-shape step",
                        "sdf_evals_per_ray_tracing": model.ray_tracer.last_stats},
             "final_loss": round(float(lo["loss"].item()), 6),
         }
