@@ -1,12 +1,13 @@
-"""SIREN activation and its initialisers (reference: code/model/embeddings/Sine.py)."""
-import numpy as np
+"""SIREN pieces used by the Fourier-filter-bank trunk (reference: code/model/embeddings/Sine.py):
+the activation sin(w0 * x) and the two uniform initialisers (weights AND biases drawn, in that order,
+so the RNG stream matches the reference constructor)."""
+import math
+
 import torch
 from torch import nn
 
 
 class Sine(nn.Module):
-    """y = sin(w0 * x)"""
-
     def __init__(self, w0):
         super().__init__()
         self.w0 = w0
@@ -15,17 +16,18 @@ class Sine(nn.Module):
         return torch.sin(input * self.w0)
 
 
+def _uniform_both(layer, bound):
+    torch.nn.init.uniform_(layer.weight, -bound, bound)
+    torch.nn.init.uniform_(layer.bias, -bound, bound)
+
+
 def sine_init(m, w0, num_input=None):
-    """hidden SIREN layer: U(+-sqrt(6/fan_in)/w0) for weight AND bias (Sine.py:14-19)"""
+    """hidden layers: U(+-sqrt(6 / fan_in) / w0)   (only when fan-in is left implicit, as the reference does)"""
     if hasattr(m, 'weight') and num_input is None:
-        bound = np.sqrt(6 / m.weight.size(-1)) / w0
-        torch.nn.init.uniform_(m.weight, -bound, bound)
-        torch.nn.init.uniform_(m.bias, -bound, bound)
+        _uniform_both(m, math.sqrt(6 / m.weight.size(-1)) / w0)
 
 
 def first_layer_sine_init(m):
-    """first SIREN layer: U(+-1/fan_in) (Sine.py:21-25)"""
+    """first layer: U(+-1 / fan_in)"""
     if hasattr(m, 'weight'):
-        bound = 1.0 / m.weight.size(-1)
-        torch.nn.init.uniform_(m.weight, -bound, bound)
-        torch.nn.init.uniform_(m.bias, -bound, bound)
+        _uniform_both(m, 1.0 / m.weight.size(-1))

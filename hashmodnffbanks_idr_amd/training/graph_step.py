@@ -11,24 +11,8 @@ makes per iteration (eikonal samples, closest-approach fractions) are copied in 
 With more than one rank the RCCL all-reduce runs eagerly between the two graphs.
 """
 import torch
-import torch.nn.functional as F
 
-
-def idr_loss_static(out, rgb_gt, eikonal_weight, mask_weight, alpha):
-    """IDRLoss (reference model/loss.py:4-70) with masks instead of boolean gathers: identical terms,
-    no `.sum() == 0` host checks (an empty selection contributes an exact 0)."""
-    net, obj = out['network_object_mask'], out['object_mask']
-    n = float(obj.shape[0])
-    sel = (net & obj).unsqueeze(-1)
-    rgb_loss = (torch.abs(out['rgb_values'] - rgb_gt.reshape(-1, 3)) * sel).sum() / n
-    g = out['grad_theta']
-    eikonal_loss = ((g.norm(2, dim=1) - 1) ** 2).mean()
-    msel = ~(net & obj)
-    logits = (-alpha * out['sdf_output']).reshape(-1)
-    bce = F.binary_cross_entropy_with_logits(logits, obj.float(), reduction='none')
-    mask_loss = (1 / alpha) * (bce * msel).sum() / n
-    loss = rgb_loss + eikonal_weight * eikonal_loss + mask_weight * mask_loss
-    return {'loss': loss, 'rgb_loss': rgb_loss, 'eikonal_loss': eikonal_loss, 'mask_loss': mask_loss}
+from ..model.loss import idr_loss_terms
 
 
 class GraphedTrainStep:
@@ -56,7 +40,7 @@ class GraphedTrainStep:
     def _fwd_bwd(self):
         s = self.static
         out = self.model.forward_static(s["input"], s["eik"], s["steps"])
-        lo = idr_loss_static(out, s["rgb"], self.loss_fn.eikonal_weight, self.loss_fn.mask_weight, self.loss_fn.alpha)
+        lo = idr_loss_terms(out, s["rgb"], self.loss_fn.eikonal_weight, self.loss_fn.mask_weight, self.loss_fn.alpha)
         lo["loss"].backward()
         return out, lo
 

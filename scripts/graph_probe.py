@@ -50,7 +50,7 @@ def run(name):
                 ((g ** 2).sum() + out.sum()).backward()
             return out
         if name in ("fwd_static", "fwd_bwd"):
-            from hashmodnffbanks_idr_amd.training.graph_step import idr_loss_static
+            from hashmodnffbanks_idr_amd.model.loss import idr_loss_terms as idr_loss_static
             model.zero_grad(set_to_none=True)
             model.train()
             out = model.forward_static(inp, eik, steps)
@@ -62,7 +62,7 @@ def run(name):
             net._packed = None
             return net.sdf(x)
         if name in ("fwd_bwd_repack", "fwd_bwd_defaultwarm"):
-            from hashmodnffbanks_idr_amd.training.graph_step import idr_loss_static
+            from hashmodnffbanks_idr_amd.model.loss import idr_loss_terms as idr_loss_static
             model.zero_grad(set_to_none=True)
             model.train()
             net._packed = None

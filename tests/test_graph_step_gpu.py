@@ -28,7 +28,7 @@ def _setup(seed=3):
 
 
 def test_static_forward_matches_dynamic_forward():
-    from hashmodnffbanks_idr_amd.training.graph_step import idr_loss_static
+    from hashmodnffbanks_idr_amd.model.loss import idr_loss_terms as idr_loss_static
     model, loss_fn, inp, gt = _setup()
     torch.manual_seed(5)
     out_d = model(inp)
