@@ -288,7 +288,7 @@ constexpr int kPts16 = 16;
 constexpr int kGroupFloats16 = kPts16 * 4;
 
 template <int FRAC>
-__global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_m16_kernel(HmLevels lv, SdfNet net,
+__global__ __launch_bounds__(kThreadsSdf, 1) void sdf_fwd_m16_kernel(HmLevels lv, SdfNet net,
                                                                       const float *__restrict__ x, int64_t n,
                                                                       const float *__restrict__ table,
                                                                       const float *__restrict__ Bf,
@@ -401,30 +401,46 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_m16_kernel(HmLevels lv
 #pragma unroll
             for (int a = 0; a < 4; ++a) acc[a] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             if (ntw > 0) {
+                // Weight stream: a 4-deep register ring (3 k-blocks = 12 KB per wave in flight).  A small
+                // batch is latency-bound on the L2 round trip of the packed weights, not on the MFMAs:
+                // with one block of look-ahead a layer took ~20 us for 6.8 us of matrix work.
+                // All loads are unconditional (clamped index) so hipcc emits counted vmcnt waits.
                 const float4 *A = reinterpret_cast<const float4 *>(Ly.w_packed_m16) + ((size_t)u0 * nb) * 64 + lane;
                 const size_t tstride = (size_t)nb * 64;  // next feature tile
-                float4 av[4];
+                const size_t o1 = (1 < ntw ? 1 : 0) * tstride, o2 = (2 < ntw ? 2 : 0) * tstride,
+                             o3 = (3 < ntw ? 3 : 0) * tstride;
+                const int nb0 = Ly.seg_blocks16[0];
+                const float *src0 = (Ly.seg_src[0] == 0) ? X : EMB;
+                const float *src1 = (Ly.seg_src[1] == 0) ? X : EMB;
+                float4 ring[4][4];
 #pragma unroll
-                for (int a = 0; a < 4; ++a) av[a] = A[(a < ntw ? a : 0) * tstride];
-                int tt = 0;
-                for (int seg = 0; seg < 2; ++seg) {
-                    const float *src = (Ly.seg_src[seg] == 0) ? X : EMB;
-                    const int nbs = Ly.seg_blocks16[seg];
-                    for (int t = 0; t < nbs; ++t, ++tt) {
-                        const float4 b = *reinterpret_cast<const float4 *>(src + (4 * t + q) * kGroupFloats16 + j * 4);
-                        const int nxt = (tt + 1 < nb) ? tt + 1 : tt;
-                        float4 an[4];
+                for (int st = 0; st < 3; ++st) {
+                    const size_t off = (size_t)min(st, nb - 1) * 64;
+                    ring[st][0] = A[off]; ring[st][1] = A[o1 + off]; ring[st][2] = A[o2 + off]; ring[st][3] = A[o3 + off];
+                }
+                for (int tt = 0; tt < nb; tt += 4) {
 #pragma unroll
-                        for (int a = 0; a < 4; ++a) an[a] = A[(a < ntw ? a : 0) * tstride + (size_t)nxt * 64];
+                    for (int u = 0; u < 4; ++u) {
+                        const int t = tt + u;
+                        if (t >= nb) break;
+                        {
+                            const size_t off = (size_t)min(t + 3, nb - 1) * 64;
+                            ring[(u + 3) & 3][0] = A[off];
+                            ring[(u + 3) & 3][1] = A[o1 + off];
+                            ring[(u + 3) & 3][2] = A[o2 + off];
+                            ring[(u + 3) & 3][3] = A[o3 + off];
+                        }
+                        const float *src = (t < nb0) ? src0 + (4 * t + q) * kGroupFloats16
+                                                     : src1 + (4 * (t - nb0) + q) * kGroupFloats16;
+                        const float4 b = *reinterpret_cast<const float4 *>(src + j * 4);
 #pragma unroll
                         for (int a = 0; a < 4; ++a) {
-                            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a].x, b.x, acc[a], 0, 0, 0);
-                            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a].y, b.y, acc[a], 0, 0, 0);
-                            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a].z, b.z, acc[a], 0, 0, 0);
-                            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a].w, b.w, acc[a], 0, 0, 0);
+                            const float4 av = ring[u][a];
+                            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b.x, acc[a], 0, 0, 0);
+                            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b.y, acc[a], 0, 0, 0);
+                            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b.z, acc[a], 0, 0, 0);
+                            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b.w, acc[a], 0, 0, 0);
                         }
-#pragma unroll
-                        for (int a = 0; a < 4; ++a) av[a] = an[a];
                     }
                 }
             }
@@ -551,7 +567,7 @@ int hm_sdf_fwd(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *x,
         HM_CHECK_ARG(lds <= 64 * 1024, "hm_sdf_fwd: network does not fit the 16-point LDS tile");
         const int64_t nmax = n < hi16 ? n : hi16;
         const int64_t tiles = (nmax + kPts16 - 1) / kPts16;
-        const int64_t cap = max_workgroups > 0 ? max_workgroups : 512;
+        const int64_t cap = max_workgroups > 0 ? max_workgroups : 256;  // one resident workgroup per CU (147 VGPRs)
         const int64_t grid = tiles < cap ? tiles : cap;
         if (frac_mode == HM_FRAC_REFERENCE)
             hipLaunchKernelGGL(sdf_fwd_m16_kernel<HM_FRAC_REFERENCE>, dim3((unsigned)grid), dim3(kThreadsSdf), lds,
