@@ -47,7 +47,7 @@ def test_encode_fwd_golden(golden, cfg):
     np.testing.assert_allclose(out[:, 3:nf], ref[:, 3:nf], atol=1e-5, rtol=0)
 
 
-@pytest.mark.parametrize("cfg,n", [("C1", 100003), ("C2", 65536 + 17)])
+@pytest.mark.parametrize("cfg,n", [("C1", 100003), ("C2", 65536 + 17), ("C4", 32768 + 5)])
 @pytest.mark.parametrize("frac", ["reference", "trilinear"])
 def test_encode_fwd_vs_oracle_large(cfg, n, frac):
     emb, table, B = _embedder(cfg, 77, 0.5, frac)
