@@ -127,7 +127,7 @@ def gather_roofline(emb, log2_n=22, iters=10, warmup=3):
     achieved = n * bpp / (avg_ms * 1e-3) / 1e9
     traffic, traffic_src = None, None
     pmc = os.path.join(ROOT, "profiles", "r01_gather_pmc.json")
-    if os.path.exists(pmc) and log2_n == 22 and emb.n_levels == 16:
+    if os.path.exists(pmc) and log2_n == 22 and emb.n_levels == 16 and emb.table.shape[0] == 5217937:
         # PMC counters cannot be read from inside this process: the number comes from the separate
         # rocprofv3 --pmc passes of `bench.py --only gather` recorded under profiles/ (same kernel, same launch)
         rec = json.load(open(pmc))
