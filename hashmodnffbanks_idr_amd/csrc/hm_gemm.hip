@@ -238,7 +238,7 @@ int hm_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const f
     const bool big = t128 >= 256;
     const int64_t bm = big ? 128 : 64, bn = big ? 128 : 64;
     static const int small_cfg = [] { const char *e = getenv("HM_GEMM_CFG"); return e ? atoi(e) : 0; }();
-    const int64_t kBK = big ? 32 : (small_cfg == 1 ? 64 : 128);
+    const int64_t kBK = big ? 32 : (small_cfg == 1 || small_cfg == 2 ? 64 : 128);
     const int64_t tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
     int64_t split = 1;
     if (tiles < 256 && K >= 256) {
@@ -276,6 +276,8 @@ int hm_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const f
         HM_GEMM_LAUNCH(2, 2, 32, 1);
     else if (small_cfg == 1)
         HM_GEMM_LAUNCH(1, 1, 64, 1);
+    else if (small_cfg == 2)
+        HM_GEMM_LAUNCH(1, 1, 64, 2);
     else
         HM_GEMM_LAUNCH(1, 1, 128, 2);
 #undef HM_GEMM_LAUNCH
