@@ -185,20 +185,35 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_kernel(HmLevels lv, Sd
             const int ntw = max(0, min(2, nt - t0));
             f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
             if (ntw > 0) {
+                // weight stream: 4-deep register ring (3 octets = 6 KB per wave in flight), unconditional
+                // clamped loads so that hipcc emits counted vmcnt waits instead of draining per octet
                 const float4 *A0 = reinterpret_cast<const float4 *>(Ly.w_packed) + ((size_t)t0 * n_oct) * 64 + lane;
                 const float4 *A1 = A0 + (ntw > 1 ? (size_t)n_oct * 64 : 0);
-                float4 a0 = A0[0], a1 = A1[0];
-                int gg = 0;
-                for (int seg = 0; seg < 2; ++seg) {
-                    const float *src = (Ly.seg_src[seg] == 0) ? X : EMB;
-                    const int no = Ly.seg_octets[seg];
-                    for (int g = 0; g < no; ++g, ++gg) {
-                        const float4 b0 = *reinterpret_cast<const float4 *>(src + (2 * g + h) * kGroupFloats + j * 4);
-                        const float4 b1 =
-                            *reinterpret_cast<const float4 *>(src + (2 * g + h) * kGroupFloats + (32 + j) * 4);
-                        const int nxt = (gg + 1 < n_oct) ? gg + 1 : gg;
-                        const float4 a0n = A0[(size_t)nxt * 64];
-                        const float4 a1n = A1[(size_t)nxt * 64];
+                const int no0 = Ly.seg_octets[0];
+                const float *src0 = (Ly.seg_src[0] == 0) ? X : EMB;
+                const float *src1 = (Ly.seg_src[1] == 0) ? X : EMB;
+                float4 r0[4], r1[4];
+#pragma unroll
+                for (int st = 0; st < 3; ++st) {
+                    const size_t off = (size_t)min(st, n_oct - 1) * 64;
+                    r0[st] = A0[off];
+                    r1[st] = A1[off];
+                }
+                for (int gg0 = 0; gg0 < n_oct; gg0 += 4) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int gg = gg0 + u;
+                        if (gg >= n_oct) break;
+                        {
+                            const size_t off = (size_t)min(gg + 3, n_oct - 1) * 64;
+                            r0[(u + 3) & 3] = A0[off];
+                            r1[(u + 3) & 3] = A1[off];
+                        }
+                        const float *src = (gg < no0) ? src0 + (2 * gg + h) * kGroupFloats
+                                                      : src1 + (2 * (gg - no0) + h) * kGroupFloats;
+                        const float4 b0 = *reinterpret_cast<const float4 *>(src + j * 4);
+                        const float4 b1 = *reinterpret_cast<const float4 *>(src + (32 + j) * 4);
+                        const float4 a0 = r0[u], a1 = r1[u];
                         acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc00, 0, 0, 0);
                         acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b1.x, acc01, 0, 0, 0);
                         acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, acc10, 0, 0, 0);
@@ -215,8 +230,6 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_kernel(HmLevels lv, Sd
                         acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b1.w, acc01, 0, 0, 0);
                         acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b0.w, acc10, 0, 0, 0);
                         acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc11, 0, 0, 0);
-                        a0 = a0n;
-                        a1 = a1n;
                     }
                 }
             }
