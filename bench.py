@@ -258,7 +258,8 @@ def main():
     rank, world, local_rank = parallel.init_distributed()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    device = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    device = torch.device("cuda", local_rank % max(n_dev, 1))  # (rehearsal: several gloo ranks may share one GPU)
     torch.cuda.set_device(device)
 
     torch.manual_seed(0)  # identical replicas on every rank

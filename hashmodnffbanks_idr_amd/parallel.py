@@ -24,7 +24,9 @@ def init_distributed(backend=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" IS RCCL on ROCm
+            # "nccl" IS RCCL on ROCm.  HM_DIST_BACKEND=gloo lets the N>1 path be rehearsed with several
+            # ranks on ONE GPU (RCCL refuses two ranks per device).
+            backend = os.environ.get("HM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
