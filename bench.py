@@ -312,7 +312,8 @@ def main():
                        "rays_per_gpu": args.rays, "global_rays": args.rays * world,
                        "parallelism": f"ray-sharded dp{world}" if world > 1 else "single GPU",
                        "step": "eager (reference-structured, dynamic shapes)" if args.no_graph
-                       else "HIP-graph captured static-shape step",
+                       else ("HIP-graph captured static-shape step" if stepper.g_fb is not None
+                             else "eager static-shape step (graph capture unavailable)"),
                        "sdf_evals_per_ray_tracing": model.ray_tracer.last_stats},
             "final_loss": round(float(lo["loss"].item()), 6),
         }

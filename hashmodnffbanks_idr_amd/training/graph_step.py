@@ -92,12 +92,24 @@ class GraphedTrainStep:
             self.model.implicit_network._packed = None  # make the capture contain the weight re-pack
             self.opt.zero_grad(set_to_none=True)
             torch.cuda.synchronize()
-            self.g_fb = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_fb):
-                self.out, self.loss_out = self._fwd_bwd()
-            self.g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_opt):
-                self._update()
+            # with RCCL alive its watchdog thread polls events; only this thread's calls must obey capture rules
+            mode = "thread_local" if (torch.distributed.is_available() and torch.distributed.is_initialized()) else "global"
+            try:
+                g_fb = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_fb, capture_error_mode=mode):
+                    self.out, self.loss_out = self._fwd_bwd()
+                g_opt = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_opt, capture_error_mode=mode):
+                    self._update()
+                self.g_fb, self.g_opt = g_fb, g_opt
+            except RuntimeError as err:  # keep training eagerly rather than die on a capture restriction
+                import warnings
+                warnings.warn(f"HIP-graph capture failed ({err}); continuing with the eager static step")
+                self.use_graph = False
+                torch.cuda.synchronize()
+                self.model.implicit_network._packed = None
+                self._eager_iteration()
+                return self.out, self.loss_out
 
         self.g_fb.replay()
         if self.reducer is not None:
