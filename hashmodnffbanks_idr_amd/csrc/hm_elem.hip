@@ -1,0 +1,152 @@
+// hm_elem.hip - fused elementwise / reduction kernels of the grad-enabled MLP path.
+//
+// nn.Softplus(beta=100, threshold=20) forward, backward and DOUBLE backward
+// (reference: model/implicit_differentiable_renderer.py:84,104-105; the double backward is what the
+// eikonal term's create_graph=True gradient needs, :116-128): autograd's generic formula for the
+// softplus double backward launches ~9 elementwise kernels per layer over [points, 512] tensors;
+// here each direction is one bandwidth-bound pass.  Also the bias-gradient column sum.
+#include "hm_common.h"
+
+namespace {
+
+constexpr int kET = 256;
+
+struct SpDeriv {
+    float s1, s2;
+};
+// s1 = d softplus/dz, s2 = d^2 softplus/dz^2 with torch's formulas (exp(beta z)/(exp(beta z)+1))
+__device__ __forceinline__ SpDeriv sp_deriv(float z, float beta, float thr) {
+    SpDeriv d;
+    const float bz = z * beta;
+    if (bz > thr) {
+        d.s1 = 1.0f;
+        d.s2 = 0.0f;
+    } else {
+        const float e = expf(bz);
+        d.s1 = e / (e + 1.0f);
+        d.s2 = beta * d.s1 * (1.0f - d.s1);
+    }
+    return d;
+}
+
+__global__ __launch_bounds__(kET) void softplus_fwd_kernel(const float *__restrict__ z, float *__restrict__ y,
+                                                           int64_t n, float beta, float thr) {
+    const int64_t i = ((int64_t)blockIdx.x * kET + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const float4 v = *reinterpret_cast<const float4 *>(z + i);
+        float4 o;
+        o.x = v.x * beta > thr ? v.x : log1pf(expf(v.x * beta)) / beta;
+        o.y = v.y * beta > thr ? v.y : log1pf(expf(v.y * beta)) / beta;
+        o.z = v.z * beta > thr ? v.z : log1pf(expf(v.z * beta)) / beta;
+        o.w = v.w * beta > thr ? v.w : log1pf(expf(v.w * beta)) / beta;
+        *reinterpret_cast<float4 *>(y + i) = o;
+    } else {
+        for (int64_t k = i; k < n; ++k) y[k] = z[k] * beta > thr ? z[k] : log1pf(expf(z[k] * beta)) / beta;
+    }
+}
+
+// gz = gy * s1(z)
+__global__ __launch_bounds__(kET) void softplus_bwd_kernel(const float *__restrict__ z, const float *__restrict__ gy,
+                                                           float *__restrict__ gz, int64_t n, float beta, float thr) {
+    const int64_t i = ((int64_t)blockIdx.x * kET + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const float4 v = *reinterpret_cast<const float4 *>(z + i);
+        const float4 g = *reinterpret_cast<const float4 *>(gy + i);
+        float4 o;
+        o.x = g.x * sp_deriv(v.x, beta, thr).s1;
+        o.y = g.y * sp_deriv(v.y, beta, thr).s1;
+        o.z = g.z * sp_deriv(v.z, beta, thr).s1;
+        o.w = g.w * sp_deriv(v.w, beta, thr).s1;
+        *reinterpret_cast<float4 *>(gz + i) = o;
+    } else {
+        for (int64_t k = i; k < n; ++k) gz[k] = gy[k] * sp_deriv(z[k], beta, thr).s1;
+    }
+}
+
+// backward of gz = gy*s1(z) for an incoming gg:  d_gy = gg*s1(z),  d_z = gg*gy*s2(z)
+__global__ __launch_bounds__(kET) void softplus_bwd_bwd_kernel(const float *__restrict__ z,
+                                                               const float *__restrict__ gy,
+                                                               const float *__restrict__ gg,
+                                                               float *__restrict__ d_gy, float *__restrict__ d_z,
+                                                               int64_t n, float beta, float thr) {
+    const int64_t i = ((int64_t)blockIdx.x * kET + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const float4 v = *reinterpret_cast<const float4 *>(z + i);
+        const float4 g = *reinterpret_cast<const float4 *>(gy + i);
+        const float4 q = *reinterpret_cast<const float4 *>(gg + i);
+        const SpDeriv a = sp_deriv(v.x, beta, thr), b = sp_deriv(v.y, beta, thr), c = sp_deriv(v.z, beta, thr),
+                      d = sp_deriv(v.w, beta, thr);
+        *reinterpret_cast<float4 *>(d_gy + i) = make_float4(q.x * a.s1, q.y * b.s1, q.z * c.s1, q.w * d.s1);
+        *reinterpret_cast<float4 *>(d_z + i) =
+            make_float4(q.x * g.x * a.s2, q.y * g.y * b.s2, q.z * g.z * c.s2, q.w * g.w * d.s2);
+    } else {
+        for (int64_t k = i; k < n; ++k) {
+            const SpDeriv a = sp_deriv(z[k], beta, thr);
+            d_gy[k] = gg[k] * a.s1;
+            d_z[k] = gg[k] * gy[k] * a.s2;
+        }
+    }
+}
+
+// out[n] += sum_m x[m, n]   (bias gradient); rows are split over blockIdx.y, fp32 atomics combine slabs
+__global__ __launch_bounds__(kET) void colsum_kernel(const float *__restrict__ x, int64_t M, int64_t N, int64_t ld,
+                                                     float *__restrict__ out, int rows_per_block) {
+    const int64_t n = (int64_t)blockIdx.x * kET + threadIdx.x;
+    if (n >= N) return;
+    const int64_t m0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t m1 = min(M, m0 + rows_per_block);
+    float acc = 0.0f;
+    for (int64_t m = m0; m < m1; ++m) acc += x[m * ld + n];
+    atomicAdd(out + n, acc);
+}
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+}  // namespace
+
+extern "C" {
+
+int hm_softplus(int order, const float *z, const float *gy, const float *gg, float *out0, float *out1, int64_t n,
+                float beta, float threshold, void *stream) {
+    HM_CHECK_ARG(order >= 0 && order <= 2, "hm_softplus: order must be 0 (forward), 1 (backward) or 2 (double backward)");
+    HM_CHECK_ARG(n >= 0, "hm_softplus: n < 0");
+    if (n == 0) return HM_OK;
+    HM_CHECK_ARG(z && out0, "hm_softplus: NULL pointer");
+    HM_CHECK_ARG(((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(out0) | reinterpret_cast<uintptr_t>(gy) |
+                   reinterpret_cast<uintptr_t>(gg) | reinterpret_cast<uintptr_t>(out1)) & 15u) == 0,
+                 "hm_softplus: pointers must be 16-byte aligned");
+    const unsigned grid = (unsigned)((n + kET * 4 - 1) / (kET * 4));
+    hipStream_t st = as_stream(stream);
+    if (order == 0) {
+        hipLaunchKernelGGL(softplus_fwd_kernel, dim3(grid), dim3(kET), 0, st, z, out0, n, beta, threshold);
+    } else if (order == 1) {
+        HM_CHECK_ARG(gy != nullptr, "hm_softplus: gy is NULL");
+        hipLaunchKernelGGL(softplus_bwd_kernel, dim3(grid), dim3(kET), 0, st, z, gy, out0, n, beta, threshold);
+    } else {
+        HM_CHECK_ARG(gy && gg && out1, "hm_softplus: NULL pointer");
+        hipLaunchKernelGGL(softplus_bwd_bwd_kernel, dim3(grid), dim3(kET), 0, st, z, gy, gg, out0, out1, n, beta,
+                           threshold);
+    }
+    HM_CHECK_LAUNCH("hm_softplus");
+    return HM_OK;
+}
+
+int hm_colsum(const float *x, int64_t M, int64_t N, int64_t ld, float *out, void *stream) {
+    HM_CHECK_ARG(M >= 0 && N >= 0 && ld >= N, "hm_colsum: bad shape");
+    if (N == 0) return HM_OK;
+    HM_CHECK_ARG(out != nullptr, "hm_colsum: out is NULL");
+    hipStream_t st = as_stream(stream);
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, st);
+    if (e != hipSuccess) return hm_fail(HM_ERR_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e));
+    if (M == 0) return HM_OK;
+    HM_CHECK_ARG(x != nullptr, "hm_colsum: x is NULL");
+    int rows = 64;
+    int64_t slabs = (M + rows - 1) / rows;
+    if (slabs > 65535) { rows = (int)((M + 65534) / 65535); slabs = (M + rows - 1) / rows; }
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((N + kET - 1) / kET), (unsigned)slabs), dim3(kET), 0, st, x, M, N,
+                       ld, out, rows);
+    HM_CHECK_LAUNCH("hm_colsum");
+    return HM_OK;
+}
+
+}  // extern "C"

@@ -172,7 +172,7 @@ class ImplicitNetwork(nn.Module):
                 x = torch.cat([x, emb], 1) / np.sqrt(2)
             x = ops.linear(x, _folded_weight(lin, self._fold_cache), lin.bias)
             if l < self.num_layers - 2:
-                x = self.softplus(x)
+                x = ops.softplus(x, self.softplus.beta, self.softplus.threshold)
         # soft clamp of the SDF column: tanh(s / (2 + LaplaceDensity(s))), density under no_grad
         s = x[..., 0]
         s = torch.tanh(s / (2 + self.dencity_net(s)))

@@ -211,7 +211,7 @@ class _MatMul(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             db = matmul(dc, a, None, True, ta) if tb else matmul(a, dc, None, not ta, False)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            dbias = dc.sum(0)
+            dbias = colsum(dc)
         return da, db, dbias, None, None
 
 
@@ -332,3 +332,75 @@ def trace_forward(desc, packed, table, B, frac_mode, tile_points, cfg, cam_loc, 
                                  dptr(steps_u), dptr(pts), dptr(mask), dptr(dists), dptr(workspace),
                                  workspace.numel(), dptr(stats), stream_ptr(ray_dirs)))
     return pts, mask, dists
+
+
+# =========================================================================================
+# fused elementwise passes (csrc/hm_elem.hip)
+# =========================================================================================
+class _ColSum(torch.autograd.Function):
+    """sum over rows (bias gradient) in one pass; its backward is a broadcast."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.rows = x.shape[0]
+        if x.stride(-1) != 1:
+            x = x.contiguous()
+        out = torch.empty(x.shape[1], dtype=torch.float32, device=x.device)
+        check(lib().hm_colsum(dptr(x), x.shape[0], x.shape[1], max(x.stride(0), 1), dptr(out), stream_ptr(x)))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.unsqueeze(0).expand(ctx.rows, -1)
+
+
+def colsum(x):
+    require_gpu(x)
+    return _ColSum.apply(x)
+
+
+def _softplus_call(order, z, gy, gg, beta, thr):
+    n = z.numel()
+    out0 = torch.empty_like(z)
+    out1 = torch.empty_like(z) if order == 2 else None
+    check(lib().hm_softplus(order, dptr(z), dptr(gy), dptr(gg), dptr(out0), dptr(out1), n, float(beta), float(thr),
+                            stream_ptr(z)))
+    return out0, out1
+
+
+class _Softplus(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, beta, thr):
+        z = z.contiguous()
+        ctx.beta, ctx.thr = beta, thr
+        ctx.save_for_backward(z)
+        return _softplus_call(0, z, None, None, beta, thr)[0]
+
+    @staticmethod
+    def backward(ctx, gy):
+        (z,) = ctx.saved_tensors
+        return _SoftplusBwd.apply(z, gy, ctx.beta, ctx.thr), None, None
+
+
+class _SoftplusBwd(torch.autograd.Function):
+    """gz = gy * s1(z); differentiable once more (d/dgy and d/dz in one fused pass)."""
+
+    @staticmethod
+    def forward(ctx, z, gy, beta, thr):
+        gy = gy.contiguous()
+        ctx.beta, ctx.thr = beta, thr
+        ctx.save_for_backward(z, gy)
+        return _softplus_call(1, z, gy, None, beta, thr)[0]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gg):
+        z, gy = ctx.saved_tensors
+        d_gy, d_z = _softplus_call(2, z, gy, gg.contiguous(), ctx.beta, ctx.thr)
+        return d_z, d_gy, None, None
+
+
+def softplus(z, beta=100.0, threshold=20.0):
+    """nn.Softplus(beta, threshold) with fused backward and double backward (third order is not provided)."""
+    require_gpu(z)
+    return _Softplus.apply(z, float(beta), float(threshold))

@@ -186,6 +186,19 @@ HM_API int hm_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, 
                        const float *B, int64_t ldb, const float *bias, float *C, int64_t ldc, int accumulate,
                        void *stream);
 
+/* ---- fused activation passes of the grad-enabled MLP path ------------------------------------
+ * nn.Softplus(beta, threshold) (implicit_differentiable_renderer.py:84) over n contiguous floats:
+ *   order 0: out0 = softplus(z)
+ *   order 1: out0 = gy * s1(z)                         (its backward; s1 = d softplus / dz)
+ *   order 2: out0 = gg * s1(z),  out1 = gg * gy * s2(z)  (backward of order 1 w.r.t. gy and z; the
+ *            double backward autograd needs for ImplicitNetwork.gradient(create_graph=True), :116-128)
+ * All pointers 16-byte aligned.                                                                   */
+HM_API int hm_softplus(int order, const float *z, const float *gy, const float *gg, float *out0, float *out1,
+                       int64_t n, float beta, float threshold, void *stream);
+
+/* out[n] = sum over rows of x[M,N] (row stride ld) - the bias gradient of an nn.Linear.          */
+HM_API int hm_colsum(const float *x, int64_t M, int64_t N, int64_t ld, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

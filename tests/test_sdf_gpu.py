@@ -169,3 +169,33 @@ def test_fused_device_side_count():
         res = ops.sdf_fwd(emb.desc, pk, x, emb.table.detach(), emb.freq_encoding.B, 0, sdf_only=True,
                           tile_points=tile, n_dev=n_dev)
         assert torch.allclose(res[:137], full[:137], rtol=1e-6, atol=1e-7)
+
+
+def test_fused_softplus_matches_torch_through_second_order():
+    from hashmodnffbanks_idr_amd import ops
+    torch.manual_seed(1)
+    z0 = (torch.randn(700, 129, device="cuda") * 0.2)
+    z0[0, :5] = torch.tensor([0.3, 0.2000001, 0.1999, -5.0, 0.0], device="cuda")   # around the threshold 100*z > 20
+
+    def run(fn):
+        z = z0.clone().requires_grad_(True)
+        w = torch.linspace(-1, 1, 129, device="cuda")
+        y = fn(z)
+        (g,) = torch.autograd.grad((y * w).sum(), z, create_graph=True)
+        loss = (g ** 2).sum() + (y ** 2).sum()
+        (gz,) = torch.autograd.grad(loss, z)
+        return y.detach(), g.detach(), gz
+
+    a = run(lambda t: ops.softplus(t, 100.0, 20.0))
+    b = run(lambda t: torch.nn.functional.softplus(t, beta=100, threshold=20))
+    for u, v in zip(a, b):
+        np.testing.assert_allclose(u.cpu().numpy(), v.cpu().numpy(), rtol=2e-5, atol=2e-6)
+
+
+def test_colsum_matches_torch():
+    from hashmodnffbanks_idr_amd import ops
+    x = torch.randn(3001, 445, device="cuda", requires_grad=True)
+    s = ops.colsum(x)
+    np.testing.assert_allclose(s.detach().cpu().numpy(), x.detach().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-4)
+    (s * torch.arange(445, device="cuda")).sum().backward()
+    assert torch.equal(x.grad[5], torch.arange(445, device="cuda").float())
