@@ -23,8 +23,9 @@ __device__ __forceinline__ SpDeriv sp_deriv(float z, float beta, float thr) {
         d.s2 = 0.0f;
     } else {
         const float e = expf(bz);
-        d.s1 = e / (e + 1.0f);
-        d.s2 = beta * d.s1 * (1.0f - d.s1);
+        const float ep1 = e + 1.0f;
+        d.s1 = e / ep1;
+        d.s2 = beta * e / (ep1 * ep1);  // = beta*s1*(1-s1) without the cancellation in (1 - s1)
     }
     return d;
 }
