@@ -172,24 +172,29 @@ def test_fused_device_side_count():
 
 
 def test_fused_softplus_matches_torch_through_second_order():
+    """Reference = torch's own softplus in float64 (truth) and in float32.  torch's fp32 double backward
+    evaluates beta*s*(1-s) with cancellation (up to ~8e-5 rel error vs fp64); the fused kernel uses
+    beta*e/(e+1)^2, so it must sit within 5e-6 of the fp64 truth and within 2e-4 of torch's fp32."""
     from hashmodnffbanks_idr_amd import ops
     torch.manual_seed(1)
     z0 = (torch.randn(700, 129, device="cuda") * 0.2)
     z0[0, :5] = torch.tensor([0.3, 0.2000001, 0.1999, -5.0, 0.0], device="cuda")   # around the threshold 100*z > 20
 
-    def run(fn):
-        z = z0.clone().requires_grad_(True)
-        w = torch.linspace(-1, 1, 129, device="cuda")
+    def run(fn, dt):
+        z = z0.clone().to(dt).requires_grad_(True)
+        w = torch.linspace(-1, 1, 129, device="cuda", dtype=dt)
         y = fn(z)
         (g,) = torch.autograd.grad((y * w).sum(), z, create_graph=True)
         loss = (g ** 2).sum() + (y ** 2).sum()
         (gz,) = torch.autograd.grad(loss, z)
-        return y.detach(), g.detach(), gz
+        return [t.detach().double().cpu().numpy() for t in (y, g, gz)]
 
-    a = run(lambda t: ops.softplus(t, 100.0, 20.0))
-    b = run(lambda t: torch.nn.functional.softplus(t, beta=100, threshold=20))
-    for u, v in zip(a, b):
-        np.testing.assert_allclose(u.cpu().numpy(), v.cpu().numpy(), rtol=2e-5, atol=2e-6)
+    mine = run(lambda t: ops.softplus(t, 100.0, 20.0), torch.float32)
+    t32 = run(lambda t: torch.nn.functional.softplus(t, beta=100, threshold=20), torch.float32)
+    t64 = run(lambda t: torch.nn.functional.softplus(t, beta=100, threshold=20), torch.float64)
+    for u, v, w in zip(mine, t64, t32):
+        np.testing.assert_allclose(u, v, rtol=5e-6, atol=2e-6)
+        np.testing.assert_allclose(u, w, rtol=2e-4, atol=2e-6)
 
 
 def test_colsum_matches_torch():
