@@ -31,6 +31,7 @@ SIGNATURES = {
     "hm_trace_workspace_bytes": (_i64, [_i64, _p]),
     "hm_trace_forward": (_int, [_p, _p, _p, _p, _int, _int, _p, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _p, _p, _p,
                                 _i64, _p, _p]),
+    "hm_pack_mlp_layer": (_int, [_p, _i64, _p, _int, _int, _int, _p, _p, _p, _p]),
     "hm_softplus": (_int, [_int, _p, _p, _p, _p, _p, _i64, C.c_float, C.c_float, _p]),
     "hm_colsum": (_int, [_p, _i64, _i64, _i64, _p, _p]),
     "hm_gemm_f32": (_int, [_int, _int, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _int, _p]),

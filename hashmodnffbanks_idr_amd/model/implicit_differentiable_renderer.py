@@ -96,6 +96,7 @@ class ImplicitNetwork(nn.Module):
             p.requires_grad = True
         self._packed = None
         self._packed_key = None
+        self._force_repack = False
         self._fold_cache = None
         self.sdf_tile_points = 0  # fused kernel tile: 0 auto (16-point tiles for small batches), 16, 64
 
@@ -128,11 +129,15 @@ class ImplicitNetwork(nn.Module):
         """Fold weight-norm and pack the MFMA operand images; cached until a parameter changes."""
         ps = self._lin_params() + [self.dencity_net.beta]
         key = tuple((p.data_ptr(), p._version) for p in ps)
-        if self._packed is None or key != self._packed_key:
+        if self._packed is None or key != self._packed_key or self._force_repack:
+            self._force_repack = False
             with torch.no_grad():
                 Ws = [_folded_weight(getattr(self, "lin" + str(l))) for l in range(self.num_layers - 1)]
                 bs = [getattr(self, "lin" + str(l)).bias for l in range(self.num_layers - 1)]
-                self._packed = ops.PackedSdf(Ws, bs, self.dims[0], self.skip_in, self._beta_value())
+                if self._packed is None or self._packed.bufs[0][0].device != Ws[0].device:
+                    self._packed = ops.PackedSdf(Ws, bs, self.dims[0], self.skip_in, self._beta_value())
+                else:
+                    self._packed.update(Ws, bs, self._beta_value())
             self._packed_key = key
         return self._packed
 

@@ -261,38 +261,61 @@ def pack_mlp_layer(W, segs, kblock=8):
 
 
 class PackedSdf:
-    """Device-resident packed weights + the [host] hm_mlp_desc for hm_sdf_fwd."""
+    """Device-resident packed weights + the [host] hm_mlp_desc for hm_sdf_fwd.
+
+    The image buffers are allocated once (stable pointers, so the descriptor stays valid across
+    optimizer steps and inside captured graphs); update() re-packs them with one kernel per layer."""
 
     def __init__(self, weights, biases, E, skip_in, beta):
         n = len(weights)
         self.desc = _lib.MlpDesc()
         self.desc.n_layers = n
-        self.desc.beta = float(beta)
-        self.keep = []
+        self.keep, self.segs, self.bufs = [], [], []
+        dev = weights[0].device
         prev_out = None
         for l in range(n):
-            W = weights[l].detach().float()
+            out_dim = weights[l].shape[0]
             if l == 0:
-                segs = [(1, E)]
+                w0, w1, srcs = E, 0, (1, 0)
             elif l in skip_in:
-                segs = [(0, prev_out), (1, E)]
+                w0, w1, srcs = prev_out, E, (0, 1)
             else:
-                segs = [(0, prev_out)]
-            Wp, n_tiles, octs, srcs = pack_mlp_layer(W, segs)
-            Wq, _, blk16, _ = pack_mlp_layer(W, segs, kblock=16)
-            b = torch.nn.functional.pad(biases[l].detach().float(), (0, n_tiles * 32 - W.shape[0])).contiguous()
-            self.keep += [Wp, Wq, b]
+                w0, w1, srcs = prev_out, 0, (0, 0)
+            assert weights[l].shape[1] == w0 + w1
+            n_tiles = (out_dim + 31) // 32
+            oct0, oct1 = (w0 + 7) // 8, (w1 + 7) // 8
+            b0, b1 = (w0 + 15) // 16, (w1 + 15) // 16
+            img8 = torch.empty(n_tiles * (oct0 + oct1) * 256, dtype=torch.float32, device=dev)
+            img16 = torch.empty(2 * n_tiles * (b0 + b1) * 256, dtype=torch.float32, device=dev)
+            bpad = torch.empty(n_tiles * 32, dtype=torch.float32, device=dev)
+            self.bufs.append((img8, img16, bpad))
+            self.segs.append((out_dim, w0, w1))
             ly = self.desc.layer[l]
-            ly.w_packed, ly.bias = Wp.data_ptr(), b.data_ptr()
-            ly.w_packed_m16 = Wq.data_ptr()
-            ly.seg_blocks16[0], ly.seg_blocks16[1] = blk16[0], blk16[1]
-            ly.out_dim, ly.n_tiles = W.shape[0], n_tiles
-            ly.seg_octets[0], ly.seg_octets[1] = octs[0], octs[1]
-            ly.seg_src[0], ly.seg_src[1] = srcs[0], srcs[1]
+            ly.w_packed, ly.bias, ly.w_packed_m16 = img8.data_ptr(), bpad.data_ptr(), img16.data_ptr()
+            ly.out_dim, ly.n_tiles = out_dim, n_tiles
+            ly.seg_octets[0], ly.seg_octets[1] = oct0, oct1
+            ly.seg_blocks16[0], ly.seg_blocks16[1] = b0, b1
+            ly.seg_src[0], ly.seg_src[1] = srcs
             ly.activation = 1 if l < n - 1 else 0
             ly.post_div_sqrt2 = 1 if (l + 1) in skip_in else 0
-            prev_out = W.shape[0]
+            prev_out = out_dim
         self.out_dim = prev_out
+        self.update(weights, biases, beta)
+
+    def update(self, weights, biases, beta):
+        self.desc.beta = float(beta)
+        for l, (img8, img16, bpad) in enumerate(self.bufs):
+            out_dim, w0, w1 = self.segs[l]
+            W = weights[l].detach()
+            b = biases[l].detach()
+            if W.dtype != torch.float32 or W.stride(-1) != 1:
+                W = W.float().contiguous()
+            if b.dtype != torch.float32 or not b.is_contiguous():
+                b = b.float().contiguous()
+            require_gpu(W, b)
+            self.keep = [W, b]
+            check(lib().hm_pack_mlp_layer(dptr(W), W.stride(0), dptr(b), out_dim, w0, w1, dptr(img8), dptr(img16),
+                                          dptr(bpad), stream_ptr(W)))
 
 
 def sdf_fwd(desc, packed, x, table, B, frac_mode=0, sdf_only=False, max_workgroups=0, tile_points=0, n_dev=None):

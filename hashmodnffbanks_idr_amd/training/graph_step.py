@@ -89,7 +89,7 @@ class GraphedTrainStep:
 
         if self.g_fb is None:
             # capture (records the kernels, does not run them), then fall through to the first replay
-            self.model.implicit_network._packed = None  # make the capture contain the weight re-pack
+            self.model.implicit_network._force_repack = True  # make the capture contain the weight re-pack
             self.opt.zero_grad(set_to_none=True)
             torch.cuda.synchronize()
             # with RCCL alive its watchdog thread polls events; only this thread's calls must obey capture rules
@@ -107,7 +107,7 @@ class GraphedTrainStep:
                 warnings.warn(f"HIP-graph capture failed ({err}); continuing with the eager static step")
                 self.use_graph = False
                 torch.cuda.synchronize()
-                self.model.implicit_network._packed = None
+                self.model.implicit_network._force_repack = True
                 self._eager_iteration()
                 return self.out, self.loss_out
 

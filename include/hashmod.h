@@ -128,6 +128,13 @@ typedef struct hm_mlp_desc {
     hm_mlp_layer layer[HM_MAX_LAYERS];
 } hm_mlp_desc;
 
+/* Builds the operand images of one layer from its folded matrix W [out_dim, seg_width0 + seg_width1]
+ * (row stride ldw) and bias: w_packed (n_tiles*n_oct*256 floats), w_packed_m16 (2*n_tiles*nb*256 floats),
+ * bias_padded (n_tiles*32 floats); seg_width1 = 0 when the layer has one input segment.             */
+HM_API int hm_pack_mlp_layer(const float *W, int64_t ldw, const float *bias, int out_dim, int seg_width0,
+                             int seg_width1, float *w_packed, float *w_packed_m16, float *bias_padded,
+                             void *stream);
+
 /* x [n,3] -> out.  out_cols == 1: only the clamped sdf, out[i*out_stride];  out_cols == last
  * layer's out_dim: the whole [sdf | feature vector] row.
  * tile_points: 64 (one workgroup per CU, throughput), 16 (small batches), 0 = choose by n.

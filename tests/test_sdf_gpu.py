@@ -204,3 +204,24 @@ def test_colsum_matches_torch():
     np.testing.assert_allclose(s.detach().cpu().numpy(), x.detach().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-4)
     (s * torch.arange(445, device="cuda")).sum().backward()
     assert torch.equal(x.grad[5], torch.arange(445, device="cuda").float())
+
+
+def test_pack_kernel_matches_layout_contract():
+    """hm_pack_mlp_layer vs the torch expression of the layout contract (ops.pack_mlp_layer)."""
+    from hashmodnffbanks_idr_amd import ops
+    torch.manual_seed(0)
+    E = 67
+    Ws = [torch.randn(512, E), torch.randn(445, 512), torch.randn(512, 445 + E), torch.randn(257, 512)]
+    bs = [torch.randn(w.shape[0]) for w in Ws]
+    pk = ops.PackedSdf([w.cuda() for w in Ws], [b.cuda() for b in bs], E, (2,), 0.9001)
+    segs = [[(1, E)], [(0, 512)], [(0, 445), (1, E)], [(0, 512)]]
+    for l, W in enumerate(Ws):
+        ref8, n_tiles, octs, srcs = ops.pack_mlp_layer(W, segs[l])
+        ref16, _, blk, _ = ops.pack_mlp_layer(W, segs[l], kblock=16)
+        img8, img16, bpad = pk.bufs[l]
+        assert torch.equal(img8.cpu(), ref8.reshape(-1)), l
+        assert torch.equal(img16.cpu(), ref16.reshape(-1)), l
+        assert torch.equal(bpad.cpu()[:W.shape[0]], bs[l]) and float(bpad.cpu()[W.shape[0]:].abs().sum()) == 0.0
+        ly = pk.desc.layer[l]
+        assert (ly.n_tiles, list(ly.seg_octets), list(ly.seg_blocks16), list(ly.seg_src)[:len(segs[l])]) == \
+            (n_tiles, octs, blk, srcs[:len(segs[l])])
