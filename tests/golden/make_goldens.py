@@ -468,7 +468,47 @@ def gen_nffb():
         save(f"nffb_sdf_{tag}", **arrays)
 
 
-GENS = dict(nffb=gen_nffb, levels=gen_levels, hash_ids=gen_hash_ids, encode=gen_encode, encode_bwd=gen_encode_bwd,
+def gen_idr_eval():
+    """IDRNetwork.forward in eval mode (the evaluation/eval.py caller: model.eval(); model(input))."""
+    seed = 61
+    cfg = "C1"
+    model = quiet(IDRNetwork, idr_conf(cfg))
+    L = P.CONFIGS[cfg][0]
+    levels, B, _, _ = P.make_embedder_state(seed, cfg, 0.05)
+    load_embedder(model.implicit_network.embed_model.embedder_obj, levels, B)
+    sd = model.implicit_network.state_dict()
+    for k, v in P.make_sdf_params(seed + 7, 3 + 4 * L, (512,) * 8, 257, (4,), 0.6, 0.1, 0.1).items():
+        sd[k] = T(v)
+    model.implicit_network.load_state_dict(sd)
+    vlevels, vB, _, _ = P.make_embedder_state(seed + 20, "viewdir", 0.5)
+    load_embedder(model.rendering_network.embed_model.embedder_obj, vlevels, vB)
+    sd = model.rendering_network.state_dict()
+    for k, v in P.make_render_params(seed + 9).items():
+        sd[k] = T(v)
+    model.rendering_network.load_state_dict(sd)
+    n = 256
+    cam, dirs = P.make_rays(seed + 50, n)
+    z = -cam[0] / np.linalg.norm(cam[0])
+    xax = np.cross(np.array([0.0, 1.0, 0.0]), z)
+    xax /= np.linalg.norm(xax)
+    yax = np.cross(z, xax)
+    R = np.stack([xax, yax, z], 1)
+    pose = np.eye(4, dtype=np.float32)
+    pose[:3, :3] = R
+    pose[:3, 3] = cam[0]
+    dc = dirs[0].astype(np.float64) @ R
+    uv = (dc[:, :2] / dc[:, 2:3]).astype(np.float32).reshape(1, n, 2)
+    intr = np.eye(4, dtype=np.float32).reshape(1, 4, 4)
+    object_mask = (np.random.RandomState(seed).uniform(0, 1, n) < 0.85).reshape(1, n)
+    inp = dict(intrinsics=T(intr), uv=T(uv), pose=T(pose.reshape(1, 4, 4)), object_mask=T(object_mask))
+    model.eval()
+    out = quiet(model, inp)
+    save("idr_eval_C1", intrinsics=intr, uv=uv, pose=pose.reshape(1, 4, 4), object_mask=object_mask,
+         seed=np.int64(seed), points=out["points"].detach().numpy(), rgb_values=out["rgb_values"].detach().numpy(),
+         sdf_output=out["sdf_output"].detach().numpy(), network_object_mask=out["network_object_mask"].numpy())
+
+
+GENS = dict(idr_eval=gen_idr_eval, nffb=gen_nffb, levels=gen_levels, hash_ids=gen_hash_ids, encode=gen_encode, encode_bwd=gen_encode_bwd,
             sdf=gen_sdf, raytrace=gen_raytrace, idr_step=gen_idr_step, init_rng=gen_init_rng,
             camera=gen_camera)
 

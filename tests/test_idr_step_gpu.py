@@ -112,3 +112,19 @@ def test_idr_training_steps(golden, merge):
                 bad = np.abs(got - ref) > 2e-6 + 1e-5 * np.abs(ref)
                 assert bad.mean() <= 0.05, (name, bad.sum(), np.abs(got - ref).max())
                 assert np.abs(got - ref).max() <= 2.5e-4, name
+
+
+def test_idr_eval_forward(golden):
+    """model.eval(); model(input) - the contract evaluation/eval.py relies on (grad_theta is None)."""
+    g = golden("idr_eval_C1")
+    model = _model(int(g["seed"]))
+    model.eval()
+    inp = {k: torch.from_numpy(g[k]).cuda() for k in ("intrinsics", "uv", "pose", "object_mask")}
+    out = model(inp)
+    assert out["grad_theta"] is None
+    mism = (out["network_object_mask"].cpu().numpy() != g["network_object_mask"]).sum()
+    assert mism <= 2
+    if mism == 0:
+        _close_mostly(out["points"].detach().cpu().numpy(), g["points"], 1e-4, 2e-5, what="points")
+        _close_mostly(out["sdf_output"].detach().cpu().numpy(), g["sdf_output"], 1e-4, 2e-5, what="sdf_output")
+        _close_mostly(out["rgb_values"].detach().cpu().numpy(), g["rgb_values"], 1e-3, 2e-4, what="rgb_values")
