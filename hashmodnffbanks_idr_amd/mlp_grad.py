@@ -1,0 +1,145 @@
+"""SDF MLP with its input-gradient as ONE autograd node with a hand-written backward.
+
+ImplicitNetwork.gradient (reference: model/implicit_differentiable_renderer.py:116-128) asks autograd for
+d sdf / d x with create_graph=True and later differentiates that gradient again (eikonal term, normals).
+Done generically, every layer contributes ~30 small autograd kernels to the double backward.  Here the pair
+
+        (e, W_0..W_{L-1}, b_0..b_{L-1})  ->  (out [N, 1+fvs],  g_e = d sdf / d e [N, E])
+
+is a single torch.autograd.Function: the forward runs the layer GEMMs (csrc/hm_gemm.hip) and the reverse sweep
+that produces g_e; the backward is the analytic reverse-over-reverse of both sweeps - per layer six GEMMs and
+four fused elementwise passes (csrc/hm_elem.hip) - so nothing needs create_graph inside.  The embedding e(x)
+stays outside (its Jacobian is handled by autograd: g = J_e(x)^T g_e), which is where the x-dependence of the
+Fourier features and - in the reference's frac mode - the zero hash-feature gradient come from.
+
+Notation (per layer l, N points):  a_l input (h_l, or cat[h_l, e]/sqrt2 at the skip), z_l = a_l W_l^T + b_l,
+h_{l+1} = softplus(z_l), s1/s2 first/second softplus derivative at z_l;
+gradient sweep: u_l = d sdf/d z_l, v_l = u_l W_l = d sdf/d a_l, u_{l-1} = v_l[:, :dh] * s1_{l-1}.
+Soft clamp of the SDF column: sdf = tanh(s / (2 + rho(s))) with rho evaluated without gradient
+(density_net.py:20-30), c = d sdf/d s = (1 - sdf^2)/(2 + rho), dc/ds = -2 sdf c / (2 + rho).
+"""
+import math
+
+import torch
+
+from . import ops
+from .ops import _softplus_call, colsum, gemm
+
+_SQRT2 = math.sqrt(2.0)
+
+
+class _SdfMlp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, e, skip_layer, beta_sp, thr_sp, beta_rho, *params):
+        L = len(params) // 2
+        Ws, bs = params[:L], params[L:]
+        N, E = e.shape
+        a_list, z_list = [], []
+        h = e
+        for l in range(L):
+            a = torch.cat([h, e], 1) / _SQRT2 if l == skip_layer else h
+            z = gemm(a, Ws[l], bs[l], False, True)
+            a_list.append(a)
+            z_list.append(z)
+            if l < L - 1:
+                h = _softplus_call(0, z, None, None, beta_sp, thr_sp)[0]
+        zL = z_list[-1]
+        s = zL[:, 0]
+        rho = (1.0 / beta_rho) * (0.5 + 0.5 * s.sign() * torch.expm1(-s.abs() / beta_rho))
+        denom = 2.0 + rho
+        sdf = torch.tanh(s / denom)
+        c = (1.0 - sdf * sdf) / denom
+        out = torch.cat([sdf.unsqueeze(-1), zL[:, 1:]], -1)
+
+        # reverse sweep for g_e = d sdf / d e
+        v_list = [None] * L
+        v = c.unsqueeze(-1) * Ws[L - 1][0:1, :]          # u_{L-1} is c on column 0 only: rank-1, no GEMM
+        ge_skip = None
+        for l in range(L - 1, -1, -1):
+            if l < L - 1:
+                v = gemm(u, Ws[l], None, False, False)    # v_l = u_l W_l
+            if l == skip_layer:
+                v = v / _SQRT2
+                dh = v.shape[1] - E
+                ge_skip = v[:, dh:]
+                v = v[:, :dh]
+            v_list[l] = v
+            if l > 0:
+                u = _softplus_call(1, z_list[l - 1], v.contiguous(), None, beta_sp, thr_sp)[0]   # u_{l-1} = v_l * s1
+        g_e = v_list[0] if ge_skip is None else v_list[0] + ge_skip
+
+        ctx.meta = (L, skip_layer, beta_sp, thr_sp, E)
+        ctx.save_for_backward(e, sdf, c, denom, *Ws, *a_list, *z_list, *[t.contiguous() for t in v_list])
+        return out, g_e
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_out, d_ge):
+        L, skip_layer, beta_sp, thr_sp, E = ctx.meta
+        sv = ctx.saved_tensors
+        e, sdf, c, denom = sv[0], sv[1], sv[2], sv[3]
+        Ws = sv[4:4 + L]
+        a_list = sv[4 + L:4 + 2 * L]
+        z_list = sv[4 + 2 * L:4 + 3 * L]
+        v_list = sv[4 + 3 * L:4 + 4 * L]
+        need_w = ctx.needs_input_grad[5:5 + L]
+        dW = [None] * L
+        db = [None] * L
+        zx = [None] * L       # extra z-bar from the adjoint of the gradient sweep
+        s_extra = None
+
+        # ---- adjoint of the gradient sweep (walks the layers upwards) --------------------------------------
+        if d_ge is not None:
+            d_ge = d_ge.contiguous()
+            vb_h = d_ge                                          # v-bar of layer 0 (hidden part)
+            for l in range(L):
+                vb = torch.cat([vb_h, d_ge], 1) / _SQRT2 if l == skip_layer else vb_h
+                if l < L - 1:
+                    ub = gemm(vb, Ws[l], None, False, True)      # u-bar_l = v-bar_l W_l^T
+                    # u_l = v_{l+1}[:, :dh] * s1_l  (recomputed; one fused pass)
+                    vh_next = v_list[l + 1]
+                    u = _softplus_call(1, z_list[l], vh_next, None, beta_sp, thr_sp)[0]
+                    if need_w[l]:
+                        dW[l] = gemm(u, vb, None, True, False)   # W-bar_l = u_l^T v-bar_l
+                    vb_h, zx[l] = _softplus_call(2, z_list[l], vh_next, ub, beta_sp, thr_sp)
+                else:
+                    w0 = Ws[l][0]                                # last layer: u = c * onehot(0)
+                    cb = vb @ w0                                 # c-bar = u-bar[:, 0]
+                    if need_w[l]:
+                        dW[l] = torch.zeros_like(Ws[l])
+                        dW[l][0] = c @ vb
+                    s_extra = cb * (-2.0 * sdf * c / denom)
+
+        # ---- backward of the forward sweep (walks the layers downwards) ------------------------------------
+        zb = d_out.clone()
+        zb[:, 0] = d_out[:, 0] * c if s_extra is None else d_out[:, 0] * c + s_extra
+        de = None
+        for l in range(L - 1, -1, -1):
+            if need_w[l]:
+                if dW[l] is None:
+                    dW[l] = gemm(zb, a_list[l], None, True, False)
+                else:
+                    gemm(zb, a_list[l], None, True, False, out=dW[l], accumulate=True)
+            if ctx.needs_input_grad[5 + L + l]:
+                db[l] = colsum(zb)
+            ab = gemm(zb, Ws[l], None, False, False)             # a-bar_l = z-bar_l W_l
+            if l == skip_layer:
+                ab = ab / _SQRT2
+                dh = ab.shape[1] - E
+                de = ab[:, dh:] if de is None else de + ab[:, dh:]
+                ab = ab[:, :dh]
+            if l > 0:
+                zb = _softplus_call(1, z_list[l - 1], ab.contiguous(), None, beta_sp, thr_sp)[0]
+                if zx[l - 1] is not None:
+                    zb = zb + zx[l - 1]
+            else:
+                de = ab if de is None else de + ab
+        d_e = de if ctx.needs_input_grad[0] else None
+        return (d_e, None, None, None, None, *dW, *db)
+
+
+def sdf_mlp(e, weights, biases, skip_layer, beta_sp, thr_sp, beta_rho):
+    """(out [N, 1+fvs], d sdf/d e [N, E]); differentiable once w.r.t. e, weights and biases."""
+    ops.require_gpu(e)
+    return _SdfMlp.apply(e.contiguous(), int(skip_layer), float(beta_sp), float(thr_sp), float(beta_rho),
+                         *weights, *biases)

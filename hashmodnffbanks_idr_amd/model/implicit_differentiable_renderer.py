@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import ops
+from .. import mlp_grad, ops
 from ..utils import rend_util
 from .custom_embedder_decoder import Custom_Embedding_Network
 from .density_net import LaplaceDensity
@@ -94,6 +94,7 @@ class ImplicitNetwork(nn.Module):
         self.softplus = nn.Softplus(beta=100)
         for p in self.parameters():
             p.requires_grad = True
+        self.use_fused_mlp_grad = True
         self._packed = None
         self._packed_key = None
         self._force_repack = False
@@ -189,8 +190,25 @@ class ImplicitNetwork(nn.Module):
 
     def forward_with_gradient(self, x):
         """(forward(x) [N,1+fvs], d sdf/d x [N,1,3]) from ONE network evaluation; the reference
-        evaluates the network twice for this pair (get_rbg_value, :321-323) with identical values."""
+        evaluates the network twice for this pair (get_rbg_value, :321-323) with identical values.
+
+        Default route: the MLP and its input-gradient are one autograd node with an analytic backward
+        (mlp_grad.sdf_mlp); only the embedding's Jacobian goes through autograd.  `use_fused_mlp_grad =
+        False` selects the generic route (autograd.grad with create_graph over the layer ops)."""
         x.requires_grad_(True)
+        if self.use_fused_mlp_grad and x.is_cuda and torch.is_grad_enabled() and len(self.skip_in) <= 1:
+            e = self.embed_fn(x) if self.embed_fn is not None else x
+            lins = [getattr(self, "lin" + str(l)) for l in range(self.num_layers - 1)]
+            Ws = [_folded_weight(lin, self._fold_cache) for lin in lins]
+            bs = [lin.bias for lin in lins]
+            skip = self.skip_in[0] if self.skip_in else -1
+            out, g_e = mlp_grad.sdf_mlp(e, Ws, bs, skip, self.softplus.beta, self.softplus.threshold,
+                                        self._beta_value())
+            if e is x:
+                g = g_e
+            else:
+                (g,) = torch.autograd.grad(e, x, g_e, create_graph=True, retain_graph=True)
+            return out, g.unsqueeze(1)
         out = self.forward(x)
         y = out[:, :1]
         d_output = torch.ones_like(y, requires_grad=False, device=y.device)

@@ -225,3 +225,30 @@ def test_pack_kernel_matches_layout_contract():
         ly = pk.desc.layer[l]
         assert (ly.n_tiles, list(ly.seg_octets), list(ly.seg_blocks16), list(ly.seg_src)[:len(segs[l])]) == \
             (n_tiles, octs, blk, srcs[:len(segs[l])])
+
+
+@pytest.mark.parametrize("tag,cfg", [("full", "C1"), ("narrow", "tiny")])
+def test_fused_mlp_grad_node_matches_generic_autograd(golden, tag, cfg):
+    """mlp_grad.sdf_mlp (analytic reverse-over-reverse) vs the generic create_graph route: outputs, input
+    gradient, and every parameter / input gradient of a loss that uses both."""
+    g = golden(f"sdf_{tag}")
+    res = []
+    for fused in (True, False):
+        net = _net(g, cfg)
+        net.train()
+        net.use_fused_mlp_grad = fused
+        x = torch.from_numpy(g["x"].copy()).cuda()
+        out, gr = net.forward_with_gradient(x)
+        R = torch.from_numpy(g["R"]).cuda()
+        loss = ((gr[:, 0, :].norm(2, dim=1) - 1) ** 2).mean() + 0.01 * (out * R).sum() + (gr[:, 0, :] * x).sum()
+        loss.backward()
+        res.append((out.detach(), gr.detach(), x.grad.clone(),
+                    {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}))
+    (o1, g1, x1, p1), (o2, g2, x2, p2) = res
+    def close(a, b, what):
+        scale = b.abs().max().item() + 1e-12
+        assert (a - b).abs().max().item() <= 2e-5 * scale, (what, (a - b).abs().max().item(), scale)
+    close(o1, o2, "out"); close(g1, g2, "gradient"); close(x1, x2, "x.grad")
+    assert p1.keys() == p2.keys()
+    for n in p1:
+        close(p1[n], p2[n], n)
