@@ -50,7 +50,13 @@ class GraphedTrainStep:
 
     def _eager_iteration(self):
         self.opt.zero_grad(set_to_none=True)
-        self.out, self.loss_out = self._fwd_bwd()
+        out, lo = self._fwd_bwd()
+        # keep VALUES only: a live autograd graph would keep this iteration's AccumulateGrad nodes (bound to
+        # this stream) alive, and a later capture on another stream would then leave the gradient
+        # accumulation outside the captured graph
+        self.out = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}
+        self.loss_out = {k: v.detach() for k, v in lo.items()}
+        del out, lo
         if self.reducer is not None:
             self.reducer()
         self._update()
@@ -94,12 +100,18 @@ class GraphedTrainStep:
             torch.cuda.synchronize()
             # with RCCL alive its watchdog thread polls events; only this thread's calls must obey capture rules
             mode = "thread_local" if (torch.distributed.is_available() and torch.distributed.is_initialized()) else "global"
+            self.out = self.loss_out = None
+            if self.side is None:
+                self.side = torch.cuda.Stream()
             try:
                 g_fb = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_fb, capture_error_mode=mode):
-                    self.out, self.loss_out = self._fwd_bwd()
+                with torch.cuda.graph(g_fb, stream=self.side, capture_error_mode=mode):   # same stream as the warm-up
+                    out, lo = self._fwd_bwd()
+                    self.out = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}
+                    self.loss_out = {k: v.detach() for k, v in lo.items()}
+                    del out, lo
                 g_opt = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_opt, capture_error_mode=mode):
+                with torch.cuda.graph(g_opt, stream=self.side, capture_error_mode=mode):
                     self._update()
                 self.g_fb, self.g_opt = g_fb, g_opt
             except RuntimeError as err:  # keep training eagerly rather than die on a capture restriction
