@@ -266,9 +266,8 @@ def main():
     model = IDRNetwork(idr_conf(CFG)).to(device)
     model.train()
     loss_fn = IDRLoss(eikonal_weight=0.1, mask_weight=100.0, alpha=50.0)
-    # dense Adam over ALL parameters incl. the hash table (reference: idr_train.py:127-128); the fused
-    # implementation is the same update in one kernel per tensor list instead of ~10 foreach passes
-    opt = torch.optim.Adam(model.parameters(), lr=1.0e-4, capturable=not args.no_graph, fused=not args.no_graph)
+    # dense Adam over ALL parameters incl. the hash table (reference: idr_train.py:127-128)
+    opt = torch.optim.Adam(model.parameters(), lr=1.0e-4, capturable=not args.no_graph)
     reducer = parallel.GradAllReducer(model.parameters()) if world > 1 else None
     inp, gt = synthetic_batch(1234 + rank, args.rays, device)
     torch.manual_seed(100 + rank)  # per-rank eikonal points / step fractions

@@ -8,12 +8,13 @@ from hashmodnffbanks_idr_amd.model.loss import IDRLoss
 from hashmodnffbanks_idr_amd.training.graph_step import GraphedTrainStep
 fused = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 torch.manual_seed(0)
-model = IDRNetwork(idr_conf("C1")).cuda(); model.train()
+CFG = sys.argv[2] if len(sys.argv) > 2 else "C1"; NR = int(sys.argv[3]) if len(sys.argv) > 3 else 512
+model = IDRNetwork(bench.idr_conf(CFG) if CFG == "C2" else idr_conf(CFG)).cuda(); model.train()
 model.implicit_network.use_fused_mlp_grad = bool(fused)
 opt = torch.optim.Adam(model.parameters(), lr=1e-4, capturable=True)
 st = GraphedTrainStep(model, IDRLoss(0.1, 100.0, 50.0), opt, warmup=2)
-inp, gt = bench.synthetic_batch(1, 512, "cuda")
-for i in range(3):
+inp, gt = bench.synthetic_batch(1, NR, "cuda")
+for i in range(int(sys.argv[4]) if len(sys.argv) > 4 else 3):
     out, lo = st.step(inp, gt)
     torch.cuda.synchronize()
     bad = {k: bool(torch.isnan(v).any()) for k, v in out.items() if torch.is_tensor(v) and v.dtype.is_floating_point}
