@@ -21,6 +21,7 @@ class GraphedTrainStep:
         self.max_norm, self.warmup_left, self.use_graph = max_norm, warmup, use_graph
         self.g_fb = self.g_opt = None
         self.side = None
+        self._stage = None
         self.static = None
         self.out = self.loss_out = None
         for grp in optimizer.param_groups:
@@ -30,12 +31,23 @@ class GraphedTrainStep:
     # -- pieces -------------------------------------------------------------------------------
     def _draws(self, n_rays, dev):
         """the reference's two CPU-generator draws of an iteration, in its order (ray_tracing.py:277 first,
-        then implicit_differentiable_renderer.py:279)"""
+        then implicit_differentiable_renderer.py:279).
+
+        They are written into PINNED staging buffers owned by this object (a ring of two, each guarded by an
+        event): the host->device copies are asynchronous, and a copy whose pageable source tensor has
+        already been freed by the time the copy engine runs is a GPU memory-access fault."""
         rt = self.model.ray_tracer
-        steps = torch.empty(rt.n_steps).uniform_(0.0, 1.0)
+        if self._stage is None:
+            self._stage = [(torch.empty(rt.n_steps).pin_memory(), torch.empty(n_rays // 2, 3).pin_memory(),
+                            torch.cuda.Event()) for _ in range(2)]
+            self._slot = 0
+        steps, eik, ev = self._stage[self._slot]
+        self._slot ^= 1
+        ev.synchronize()          # the copy that last read this slot has completed
+        steps.uniform_(0.0, 1.0)
         bb = self.model.object_bounding_sphere
-        eik = torch.empty(n_rays // 2, 3).uniform_(-bb, bb)
-        return steps, eik
+        eik.uniform_(-bb, bb)
+        return steps, eik, ev
 
     def _fwd_bwd(self):
         s = self.static
@@ -65,17 +77,19 @@ class GraphedTrainStep:
     def step(self, model_input, ground_truth):
         dev = model_input["uv"].device
         n_rays = model_input["uv"].shape[0] * model_input["uv"].shape[1]
-        steps, eik = self._draws(n_rays, dev)
+        steps, eik, ev = self._draws(n_rays, dev)
         if self.static is None:
-            self.static = {"input": {k: v.clone() for k, v in model_input.items()},
-                           "rgb": ground_truth["rgb"].to(dev).clone(), "eik": eik.to(dev), "steps": steps.to(dev)}
-        else:
-            s = self.static
-            for k, v in model_input.items():
-                s["input"][k].copy_(v, non_blocking=True)
-            s["rgb"].copy_(ground_truth["rgb"], non_blocking=True)
-            s["eik"].copy_(eik, non_blocking=True)
-            s["steps"].copy_(steps, non_blocking=True)
+            self.static = {"input": {k: v.to(dev).clone() for k, v in model_input.items()},
+                           "rgb": ground_truth["rgb"].to(dev).clone(),
+                           "eik": torch.empty(eik.shape, device=dev), "steps": torch.empty(steps.shape, device=dev)}
+        s = self.static
+        for k, v in model_input.items():
+            if v.data_ptr() != s["input"][k].data_ptr():
+                s["input"][k].copy_(v, non_blocking=v.is_cuda)   # host sources are copied synchronously
+        s["rgb"].copy_(ground_truth["rgb"], non_blocking=ground_truth["rgb"].is_cuda)
+        s["eik"].copy_(eik, non_blocking=True)
+        s["steps"].copy_(steps, non_blocking=True)
+        ev.record()
 
         if not self.use_graph or self.warmup_left > 0:
             self.warmup_left -= 1
