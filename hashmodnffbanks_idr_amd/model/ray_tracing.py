@@ -45,9 +45,9 @@ class RayTracing(nn.Module):
         """Counters of the last call (reads them back from the device on access)."""
         if self._stats_dev is not None:
             v = self._stats_dev.tolist()
+            # (the device tensor is kept: inside a captured graph it is refreshed by every replay)
             self._stats = {"rays": self._stats.get("rays"), "sampler_rays": v[0], "secant_rays": v[2],
                            "mask_loss_rays": v[3], "sdf_evals": v[6], "unfinished": v[7]}
-            self._stats_dev = None
         return self._stats
 
     def _fused_network(self, sdf, ray_directions):
