@@ -265,6 +265,8 @@ def main():
     torch.manual_seed(0)  # identical replicas on every rank
     model = IDRNetwork(idr_conf(CFG)).to(device)
     model.train()
+    if os.environ.get("HM_FUSED_MLP_GRAD", "1") == "0":   # debugging switch: generic autograd route for gradient()
+        model.implicit_network.use_fused_mlp_grad = False
     loss_fn = IDRLoss(eikonal_weight=0.1, mask_weight=100.0, alpha=50.0)
     # dense Adam over ALL parameters incl. the hash table (reference: idr_train.py:127-128)
     opt = torch.optim.Adam(model.parameters(), lr=1.0e-4, capturable=not args.no_graph)
