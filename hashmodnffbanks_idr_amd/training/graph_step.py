@@ -10,15 +10,21 @@ torch.cuda.CUDAGraph (hipGraph underneath) and replayed; only the two CPU-genera
 makes per iteration (eikonal samples, closest-approach fractions) are copied in before each replay.
 With more than one rank the RCCL all-reduce runs eagerly between the two graphs.
 """
+import os
+
 import torch
 
 from ..model.loss import idr_loss_terms
 
 
 class GraphedTrainStep:
-    def __init__(self, model, loss_fn, optimizer, reducer=None, max_norm=1.0, warmup=3, use_graph=True):
+    def __init__(self, model, loss_fn, optimizer, reducer=None, max_norm=1.0, warmup=3, use_graph=True,
+                 sync_each_step=None):
         self.model, self.loss_fn, self.opt, self.reducer = model, loss_fn, optimizer, reducer
         self.max_norm, self.warmup_left, self.use_graph = max_norm, warmup, use_graph
+        if sync_each_step is None:
+            sync_each_step = os.environ.get("HM_GRAPH_SYNC", "1") != "0"
+        self.sync_each_step = sync_each_step
         self.g_fb = self.g_opt = None
         self.side = None
         self._stage = None
@@ -118,16 +124,24 @@ class GraphedTrainStep:
             if self.side is None:
                 self.side = torch.cuda.Stream()
             try:
+                dump = os.environ.get("HM_GRAPH_DUMP")       # directory for hipGraphDebugDotPrint output (debugging)
                 g_fb = torch.cuda.CUDAGraph()
+                if dump:
+                    g_fb.enable_debug_mode()
                 with torch.cuda.graph(g_fb, stream=self.side, capture_error_mode=mode):   # same stream as the warm-up
                     out, lo = self._fwd_bwd()
                     self.out = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}
                     self.loss_out = {k: v.detach() for k, v in lo.items()}
                     del out, lo
                 g_opt = torch.cuda.CUDAGraph()
+                if dump:
+                    g_opt.enable_debug_mode()
                 with torch.cuda.graph(g_opt, stream=self.side, capture_error_mode=mode):
                     self._update()
                 self.g_fb, self.g_opt = g_fb, g_opt
+                if dump:
+                    g_fb.debug_dump(os.path.join(dump, "g_fb.dot"))
+                    g_opt.debug_dump(os.path.join(dump, "g_opt.dot"))
             except RuntimeError as err:  # keep training eagerly rather than die on a capture restriction
                 import warnings
                 warnings.warn(f"HIP-graph capture failed ({err}); continuing with the eager static step")
@@ -141,4 +155,9 @@ class GraphedTrainStep:
         if self.reducer is not None:
             self.reducer()
         self.g_opt.replay()
+        if self.sync_each_step:
+            # Replays left running ahead of the host, with a device-wide synchronisation somewhere in between,
+            # ended in GPU memory faults a few iterations later on ROCm 7.0 ("graph replay fault");
+            # iterations that each end in a device synchronisation never did.  Cost: one launch latency per step.
+            torch.cuda.synchronize()
         return self.out, self.loss_out
