@@ -39,6 +39,24 @@ int hm_fail(int code, const std::string &msg);
     } while (0)
 
 #ifdef __HIPCC__
+// Small device-side fills / copies as ordinary KERNELS.  hipMemsetAsync / hipMemcpyAsync become MEMSET / MEMCPY
+// nodes when the call is recorded into a HIP graph; on ROCm 7.0 those nodes were seen to lose their place
+// relative to the neighbouring kernel nodes when a graph is re-launched back to back (zeroed cursors in the
+// middle of a ray search -> wild indices -> GPU memory fault).  Kernel nodes keep their order.
+static __global__ __launch_bounds__(256) void hm_zero_u32_kernel(uint32_t *p, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+static __global__ __launch_bounds__(64) void hm_copy_u32_kernel(uint32_t *dst, const uint32_t *src, int n) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+static inline void hm_zero_u32_async(void *p, int64_t n_words, hipStream_t st) {
+    if (n_words > 0)
+        hipLaunchKernelGGL(hm_zero_u32_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st,
+                           static_cast<uint32_t *>(p), n_words);
+}
+
 // hash of one voxel corner: reference hashGridEmbedding.py:32-40 restated in uint32
 // (primes 1, 3, 2654435761; xor fold; unsigned modulo by the level's row count).
 __device__ __forceinline__ uint32_t hm_mod_rows(uint32_t h, uint32_t rows, uint32_t magic) {

@@ -137,8 +137,7 @@ int hm_colsum(const float *x, int64_t M, int64_t N, int64_t ld, float *out, void
     if (N == 0) return HM_OK;
     HM_CHECK_ARG(out != nullptr, "hm_colsum: out is NULL");
     hipStream_t st = as_stream(stream);
-    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, st);
-    if (e != hipSuccess) return hm_fail(HM_ERR_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e));
+    hm_zero_u32_async(out, N, st);
     if (M == 0) return HM_OK;
     HM_CHECK_ARG(x != nullptr, "hm_colsum: x is NULL");
     int rows = 64;

@@ -428,8 +428,7 @@ int hm_trace_forward(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const flo
     a.ls_iters = cfg->line_step_iters; a.max_it = cfg->sphere_tracing_iters; a.n_steps = cfg->n_steps;
     a.n_secant = cfg->n_secant_steps; a.training = cfg->training;
 
-    hipError_t e = hipMemsetAsync(a.w.cnt, 0, sizeof(int32_t) * C_COUNT, st);
-    if (e != hipSuccess) return hm_fail(HM_ERR_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e));
+    hm_zero_u32_async(a.w.cnt, C_COUNT, st);
     const unsigned g_rays = (unsigned)((n_rays + kTB - 1) / kTB);
     const unsigned g_samp = (unsigned)((n_rays * cfg->n_steps + kTB - 1) / kTB);
 
@@ -478,8 +477,8 @@ int hm_trace_forward(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const flo
     }
     hipLaunchKernelGGL(count_evals_kernel, dim3(1), dim3(64), 0, st, a.w.cnt, rounds + 1, cfg->n_secant_steps);
     if (stats_out) {
-        e = hipMemcpyAsync(stats_out, a.w.cnt + C_NSAMP, sizeof(int32_t) * 8, hipMemcpyDeviceToDevice, st);
-        if (e != hipSuccess) return hm_fail(HM_ERR_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e));
+        hipLaunchKernelGGL(hm_copy_u32_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<uint32_t *>(stats_out),
+                           reinterpret_cast<const uint32_t *>(a.w.cnt + C_NSAMP), 8);
     }
     HM_CHECK_LAUNCH("hm_trace_forward");
     return HM_OK;

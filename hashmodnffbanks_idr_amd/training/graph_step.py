@@ -125,7 +125,7 @@ class GraphedTrainStep:
                 self.side = torch.cuda.Stream()
             try:
                 dump = os.environ.get("HM_GRAPH_DUMP")       # directory for hipGraphDebugDotPrint output (debugging)
-                g_fb = torch.cuda.CUDAGraph()
+                g_fb = torch.cuda.CUDAGraph(keep_graph=True) if dump else torch.cuda.CUDAGraph()
                 if dump:
                     g_fb.enable_debug_mode()
                 with torch.cuda.graph(g_fb, stream=self.side, capture_error_mode=mode):   # same stream as the warm-up
@@ -133,7 +133,7 @@ class GraphedTrainStep:
                     self.out = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}
                     self.loss_out = {k: v.detach() for k, v in lo.items()}
                     del out, lo
-                g_opt = torch.cuda.CUDAGraph()
+                g_opt = torch.cuda.CUDAGraph(keep_graph=True) if dump else torch.cuda.CUDAGraph()
                 if dump:
                     g_opt.enable_debug_mode()
                 with torch.cuda.graph(g_opt, stream=self.side, capture_error_mode=mode):
