@@ -9,7 +9,8 @@ import os
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libhashmod.so")
+# HM_LIB_PATH: kernel-experiment builds of the same ABI (profiling only)
+LIB_PATH = os.environ.get("HM_LIB_PATH") or os.path.join(_PKG, "libhashmod.so")
 _lib = None
 
 _p = C.c_void_p

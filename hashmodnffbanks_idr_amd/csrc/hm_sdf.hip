@@ -298,19 +298,14 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_kernel(HmLevels lv, Sd
 // identity: lane (point j, quarter q) holds features 4q..4q+3 of a tile = one k-group.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kPts16 = 16;
+constexpr int kRing16 = 4;   // weight ring depth of the 16-point kernel (k-blocks)
 constexpr int kGroupFloats16 = kPts16 * 4;
 
 template <int FRAC>
-__global__ __launch_bounds__(kThreadsSdf, 1) void sdf_fwd_m16_kernel(HmLevels lv, SdfNet net,
-                                                                      const float *__restrict__ x, int64_t n,
-                                                                      const float *__restrict__ table,
-                                                                      const float *__restrict__ Bf,
-                                                                      float *__restrict__ out, int64_t out_stride,
-                                                                      int out_cols, const int32_t *__restrict__ n_dev, int64_t run_min,
-                                                                      int64_t run_max) {
-    extern __shared__ __align__(16) float lds[];
-    if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));
-    if (n < run_min || n > run_max) return;
+__device__ __forceinline__ void sdf_m16_body(const HmLevels &lv, const SdfNet &net, const float *__restrict__ x,
+                                             int64_t n, const float *__restrict__ table,
+                                             const float *__restrict__ Bf, float *__restrict__ out,
+                                             int64_t out_stride, int out_cols, float *lds) {
     const int emb_groups16 = ((lv.E + 15) / 16) * 4;
     float *X = lds;
     float *EMB = lds + (size_t)net.x_groups * kGroupFloats16;
@@ -375,6 +370,21 @@ __global__ __launch_bounds__(kThreadsSdf, 1) void sdf_fwd_m16_kernel(HmLevels lv
         }
         __syncthreads();
 
+        float4 ring[kRing16][4];
+        bool ring_ready = false;
+        auto prefetch16 = [&](int l) {
+            const hm_mlp_layer &Lp = net.layer[l];
+            const int nbp = Lp.seg_blocks16[0] + Lp.seg_blocks16[1];
+            const int ntp = max(0, min(4, Lp.n_tiles * 2 - 4 * wave));
+            const float4 *Ap = reinterpret_cast<const float4 *>(Lp.w_packed_m16) + ((size_t)(4 * wave) * nbp) * 64 + lane;
+            const size_t ts = (size_t)nbp * 64;
+            const size_t p1 = (1 < ntp ? 1 : 0) * ts, p2 = (2 < ntp ? 2 : 0) * ts, p3 = (3 < ntp ? 3 : 0) * ts;
+#pragma unroll
+            for (int st = 0; st < kRing16 - 1; ++st) {
+                const size_t off = (size_t)min(st, nbp - 1) * 64;
+                ring[st][0] = Ap[off]; ring[st][1] = Ap[p1 + off]; ring[st][2] = Ap[p2 + off]; ring[st][3] = Ap[p3 + off];
+            }
+        };
         for (int li = 0; li < net.n_layers; ++li) {
             const hm_mlp_layer &Ly = net.layer[li];
             const int nb = Ly.seg_blocks16[0] + Ly.seg_blocks16[1];  // 16-wide k blocks
@@ -414,9 +424,11 @@ __global__ __launch_bounds__(kThreadsSdf, 1) void sdf_fwd_m16_kernel(HmLevels lv
 #pragma unroll
             for (int a = 0; a < 4; ++a) acc[a] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             if (ntw > 0) {
-                // Weight stream: a 4-deep register ring (3 k-blocks = 12 KB per wave in flight).  A small
-                // batch is latency-bound on the L2 round trip of the packed weights, not on the MFMAs:
-                // with one block of look-ahead a layer took ~20 us for 6.8 us of matrix work.
+                // Weight stream: a kRing16-deep register ring (kRing16-1 k-blocks of 4 KB per wave in flight).
+                // A small batch is bound by the round trip of the packed weights (7.9 MB per workgroup, served
+                // from the Infinity Cache at ~2 us), not by the MFMAs: bytes in flight per CU set the rate.
+                // The first kRing16-1 blocks of a layer were requested before the previous layer's epilogue
+                // (`prefetch16` below), so the pipeline does not drain at layer boundaries.
                 // All loads are unconditional (clamped index) so hipcc emits counted vmcnt waits.
                 const float4 *A = reinterpret_cast<const float4 *>(Ly.w_packed_m16) + ((size_t)u0 * nb) * 64 + lane;
                 const size_t tstride = (size_t)nb * 64;  // next feature tile
@@ -425,23 +437,19 @@ __global__ __launch_bounds__(kThreadsSdf, 1) void sdf_fwd_m16_kernel(HmLevels lv
                 const int nb0 = Ly.seg_blocks16[0];
                 const float *src0 = (Ly.seg_src[0] == 0) ? X : EMB;
                 const float *src1 = (Ly.seg_src[1] == 0) ? X : EMB;
-                float4 ring[4][4];
+                if (!ring_ready) prefetch16(li);
+                ring_ready = false;
+                for (int tt = 0; tt < nb; tt += kRing16) {
 #pragma unroll
-                for (int st = 0; st < 3; ++st) {
-                    const size_t off = (size_t)min(st, nb - 1) * 64;
-                    ring[st][0] = A[off]; ring[st][1] = A[o1 + off]; ring[st][2] = A[o2 + off]; ring[st][3] = A[o3 + off];
-                }
-                for (int tt = 0; tt < nb; tt += 4) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < kRing16; ++u) {
                         const int t = tt + u;
                         if (t >= nb) break;
                         {
-                            const size_t off = (size_t)min(t + 3, nb - 1) * 64;
-                            ring[(u + 3) & 3][0] = A[off];
-                            ring[(u + 3) & 3][1] = A[o1 + off];
-                            ring[(u + 3) & 3][2] = A[o2 + off];
-                            ring[(u + 3) & 3][3] = A[o3 + off];
+                            const size_t off = (size_t)min(t + kRing16 - 1, nb - 1) * 64;
+                            ring[(u + kRing16 - 1) % kRing16][0] = A[off];
+                            ring[(u + kRing16 - 1) % kRing16][1] = A[o1 + off];
+                            ring[(u + kRing16 - 1) % kRing16][2] = A[o2 + off];
+                            ring[(u + kRing16 - 1) % kRing16][3] = A[o3 + off];
                         }
                         const float *src = (t < nb0) ? src0 + (4 * t + q) * kGroupFloats16
                                                      : src1 + (4 * (t - nb0) + q) * kGroupFloats16;
@@ -455,6 +463,14 @@ __global__ __launch_bounds__(kThreadsSdf, 1) void sdf_fwd_m16_kernel(HmLevels lv
                             acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b.w, acc[a], 0, 0, 0);
                         }
                     }
+                }
+            }
+            // request the next layer's first blocks now: they travel while this layer's epilogue and the two
+            // barriers run (weights do not depend on the activations)
+            if (li + 1 < net.n_layers && !(li + 1 == net.n_layers - 1 && out_cols == 1)) {
+                if (2 * net.layer[li + 1].n_tiles - 4 * wave > 0) {
+                    prefetch16(li + 1);
+                    ring_ready = true;
                 }
             }
             __syncthreads();
@@ -495,6 +511,275 @@ __global__ __launch_bounds__(kThreadsSdf, 1) void sdf_fwd_m16_kernel(HmLevels lv
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// 8-point tiles for the smallest batches (late sphere-tracing rounds, secant steps: <= 2048 live points).
+// A 16-point tile costs the same MFMA time however few of its points are live (8 x 13.6 us per network on
+// one CU); with 8 points per workgroup the matrix work halves and the call is bound by the weight stream
+// alone.  v_mfma_f32_4x4x1_16b_f32 computes 16 independent 4x4 outer products: lane l = 16q + j supplies
+//   A = W[16u + j][k]  (k in quarter q of the 16-wide k-block: the SAME packed image as the 16-point kernel)
+//   B = X[point l & 3][k]
+// and block (q, j / 4) accumulates, for its four features and four points, the partial sum over the k of
+// quarter q; the four quarters are added with two lane exchanges at the end of the layer, which also hand
+// each lane exactly one (feature quad, point) of the next layer's X image.
+constexpr int kPts8 = 8;
+constexpr int kRing8 = 5;    // weight ring depth of the 8-point body (k-blocks)
+constexpr int kGroupFloats8 = kPts8 * 4;
+
+template <int FRAC>
+__device__ __forceinline__ void sdf_m8_body(const HmLevels &lv, const SdfNet &net, const float *__restrict__ x,
+                                            int64_t n, const float *__restrict__ table,
+                                            const float *__restrict__ Bf, float *__restrict__ out,
+                                            int64_t out_stride, int out_cols, float *lds) {
+    const int emb_groups16 = ((lv.E + 15) / 16) * 4;
+    float *X = lds;
+    float *EMB = lds + (size_t)net.x_groups * kGroupFloats8;
+    float *SX = EMB + (size_t)emb_groups16 * kGroupFloats8;  // [8][3] (+ pad)
+    float *RED = SX + kPts8 * 4;                              // [8 waves][8 points]
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    const int q = lane >> 4;         // k quarter of the A operand
+    const int jj = (lane & 15) >> 2; // feature quad within the 16-feature tile
+    const int p4 = lane & 3;         // point within a group of four
+    const int L = lv.L, F = lv.F, E = lv.E;
+    const int64_t n_tiles = (n + kPts8 - 1) / kPts8;
+
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t base = tile * kPts8;
+        const int cnt = (int)min((int64_t)kPts8, n - base);
+        __syncthreads();
+        if (tid < kPts8 * 3) SX[tid] = (tid < cnt * 3) ? x[base * 3 + tid] : 0.0f;
+        __syncthreads();
+
+        // ---- encode: thread -> (point p, slot c0); 64 slots cover channels / levels
+        {
+            const int p = tid & (kPts8 - 1);
+            const int c0 = tid >> 3;  // 0..63
+            const float x0 = SX[p * 3], x1 = SX[p * 3 + 1], x2 = SX[p * 3 + 2];
+            auto put = [&](int e, float v) { EMB[(e >> 2) * kGroupFloats8 + p * 4 + (e & 3)] = v; };
+            if (c0 == 0) {
+                put(0, x0); put(1, x1); put(2, x2);
+                for (int e = E; e < emb_groups16 * 4; ++e) put(e, 0.0f);
+            }
+            const float two_pi = 6.283185307179586f;
+            const float s0 = __fmul_rn(two_pi, x0), s1 = __fmul_rn(two_pi, x1), s2 = __fmul_rn(two_pi, x2);
+            for (int c = c0; c < L; c += 64) {
+                float a = __fmul_rn(s0, Bf[c]);
+                a = __fmaf_rn(s1, Bf[L + c], a);
+                a = __fmaf_rn(s2, Bf[2 * L + c], a);
+                float sn, cs;
+                sincosf(a, &sn, &cs);
+                put(3 + c, sn);
+                put(3 + L + c, cs);
+            }
+            for (int l = c0; l < L; l += 64) {
+                float acc[8];
+                for (int f = 0; f < F; ++f) acc[f] = 0.0f;
+                const float *tl = table + (size_t)lv.row_off[l] * F;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    uint32_t ux, uy, uz;
+                    float wx, wy, wz;
+                    corner<FRAC>(x0, lv.res[l], c & 1, ux, wx);
+                    corner<FRAC>(x1, lv.res[l], (c >> 1) & 1, uy, wy);
+                    corner<FRAC>(x2, lv.res[l], (c >> 2) & 1, uz, wz);
+                    const float w = __fmul_rn(__fmul_rn(wx, wy), wz);
+                    if (w != 0.0f) {
+                        const uint32_t id = hm_mod_rows(hm_hash3(ux, uy, uz), lv.rows[l], lv.magic[l]);
+                        for (int f = 0; f < F; ++f) acc[f] = __fadd_rn(acc[f], __fmul_rn(tl[(size_t)id * F + f], w));
+                    }
+                }
+                for (int f = 0; f < F; ++f) put(3 + 2 * L + l * F + f, acc[f]);
+            }
+        }
+        __syncthreads();
+
+        float4 ring[kRing8][4];
+        bool ring_ready = false;
+        auto prefetch8 = [&](int l) {
+            const hm_mlp_layer &Lp = net.layer[l];
+            const int nbp = Lp.seg_blocks16[0] + Lp.seg_blocks16[1];
+            const int ntp = max(0, min(4, Lp.n_tiles * 2 - 4 * wave));
+            const float4 *Ap = reinterpret_cast<const float4 *>(Lp.w_packed_m16) + ((size_t)(4 * wave) * nbp) * 64 + lane;
+            const size_t ts = (size_t)nbp * 64;
+            const size_t p1 = (1 < ntp ? 1 : 0) * ts, p2 = (2 < ntp ? 2 : 0) * ts, p3 = (3 < ntp ? 3 : 0) * ts;
+#pragma unroll
+            for (int st = 0; st < kRing8 - 1; ++st) {
+                const size_t off = (size_t)min(st, nbp - 1) * 64;
+                ring[st][0] = Ap[off]; ring[st][1] = Ap[p1 + off]; ring[st][2] = Ap[p2 + off]; ring[st][3] = Ap[p3 + off];
+            }
+        };
+        for (int li = 0; li < net.n_layers; ++li) {
+            const hm_mlp_layer &Ly = net.layer[li];
+            const int nb = Ly.seg_blocks16[0] + Ly.seg_blocks16[1];  // 16-wide k blocks
+            if (li == net.n_layers - 1 && out_cols == 1) {
+                // sdf-only last layer: VALU dot product.  lane -> (point, k quarter, block parity)
+                const float4 *W0 = reinterpret_cast<const float4 *>(Ly.w_packed_m16);
+                const int pp = lane & 7, qq = (lane >> 3) & 3, th = lane >> 5;
+                float part = 0.0f;
+                int t0 = 0;
+                for (int seg = 0; seg < 2; ++seg) {
+                    const float *src = (Ly.seg_src[seg] == 0) ? X : EMB;
+                    const int nbs = Ly.seg_blocks16[seg];
+                    for (int t = 2 * wave + th; t < nbs; t += 2 * kWaves) {
+                        const float4 xv = *reinterpret_cast<const float4 *>(src + (4 * t + qq) * kGroupFloats8 + pp * 4);
+                        const float4 wv = W0[(size_t)(t0 + t) * 64 + qq * 16];
+                        part = __fmaf_rn(xv.x, wv.x, part);
+                        part = __fmaf_rn(xv.y, wv.y, part);
+                        part = __fmaf_rn(xv.z, wv.z, part);
+                        part = __fmaf_rn(xv.w, wv.w, part);
+                    }
+                    t0 += nbs;
+                }
+                part += __shfl_xor(part, 8);
+                part += __shfl_xor(part, 16);
+                part += __shfl_xor(part, 32);
+                if (lane < kPts8) RED[wave * kPts8 + lane] = part;
+                __syncthreads();
+                if (tid < cnt) {
+                    float sacc = Ly.bias[0];
+                    for (int w8 = 0; w8 < kWaves; ++w8) sacc += RED[w8 * kPts8 + tid];
+                    out[(base + tid) * out_stride] = sdf_clamp(sacc, net.beta);
+                }
+                break;
+            }
+            const int nt16 = Ly.n_tiles * 2;
+            const int u0 = 4 * wave;
+            const int ntw = max(0, min(4, nt16 - u0));
+            f32x4 acc0[4], acc1[4];   // points 0-3 / 4-7
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                acc0[a] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                acc1[a] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+            if (ntw > 0) {
+                const float4 *A = reinterpret_cast<const float4 *>(Ly.w_packed_m16) + ((size_t)u0 * nb) * 64 + lane;
+                const size_t tstride = (size_t)nb * 64;
+                const size_t o1 = (1 < ntw ? 1 : 0) * tstride, o2 = (2 < ntw ? 2 : 0) * tstride,
+                             o3 = (3 < ntw ? 3 : 0) * tstride;
+                const int nb0 = Ly.seg_blocks16[0];
+                const float *src0 = (Ly.seg_src[0] == 0) ? X : EMB;
+                const float *src1 = (Ly.seg_src[1] == 0) ? X : EMB;
+                if (!ring_ready) prefetch8(li);
+                ring_ready = false;
+                for (int tt = 0; tt < nb; tt += kRing8) {
+#pragma unroll
+                    for (int u = 0; u < kRing8; ++u) {
+                        const int t = tt + u;
+                        if (t >= nb) break;
+                        {
+                            const size_t off = (size_t)min(t + kRing8 - 1, nb - 1) * 64;
+                            ring[(u + kRing8 - 1) % kRing8][0] = A[off];
+                            ring[(u + kRing8 - 1) % kRing8][1] = A[o1 + off];
+                            ring[(u + kRing8 - 1) % kRing8][2] = A[o2 + off];
+                            ring[(u + kRing8 - 1) % kRing8][3] = A[o3 + off];
+                        }
+                        const float *src = (t < nb0) ? src0 + (4 * t + q) * kGroupFloats8
+                                                     : src1 + (4 * (t - nb0) + q) * kGroupFloats8;
+                        const float4 b0 = *reinterpret_cast<const float4 *>(src + p4 * 4);
+                        const float4 b1 = *reinterpret_cast<const float4 *>(src + (p4 + 4) * 4);
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) {
+                            const float4 av = ring[u][a];
+                            acc0[a] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.x, b0.x, acc0[a], 0, 0, 0);
+                            acc1[a] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.x, b1.x, acc1[a], 0, 0, 0);
+                            acc0[a] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.y, b0.y, acc0[a], 0, 0, 0);
+                            acc1[a] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.y, b1.y, acc1[a], 0, 0, 0);
+                            acc0[a] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.z, b0.z, acc0[a], 0, 0, 0);
+                            acc1[a] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.z, b1.z, acc1[a], 0, 0, 0);
+                            acc0[a] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.w, b0.w, acc0[a], 0, 0, 0);
+                            acc1[a] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.w, b1.w, acc1[a], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            if (li + 1 < net.n_layers && !(li + 1 == net.n_layers - 1 && out_cols == 1)) {
+                if (2 * net.layer[li + 1].n_tiles - 4 * wave > 0) {
+                    prefetch8(li + 1);
+                    ring_ready = true;
+                }
+            }
+            // add the four k quarters; lane q ends up with the complete sums of feature tile a == q
+            // (exchange across lane bit 5 keeps tiles {0,1} or {2,3}, across bit 4 keeps one of the pair)
+            f32x4 r0, r1;
+            {
+                const bool hi2 = (q & 2) != 0, hi1 = (q & 1) != 0;
+                f32x4 k0[2], k1[2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float keep0 = hi2 ? acc0[a + 2][r] : acc0[a][r], send0 = hi2 ? acc0[a][r] : acc0[a + 2][r];
+                        const float keep1 = hi2 ? acc1[a + 2][r] : acc1[a][r], send1 = hi2 ? acc1[a][r] : acc1[a + 2][r];
+                        k0[a][r] = keep0 + __shfl_xor(send0, 32);
+                        k1[a][r] = keep1 + __shfl_xor(send1, 32);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float keep0 = hi1 ? k0[1][r] : k0[0][r], send0 = hi1 ? k0[0][r] : k0[1][r];
+                    const float keep1 = hi1 ? k1[1][r] : k1[0][r], send1 = hi1 ? k1[0][r] : k1[1][r];
+                    r0[r] = keep0 + __shfl_xor(send0, 16);
+                    r1[r] = keep1 + __shfl_xor(send1, 16);
+                }
+            }
+            __syncthreads();
+            const bool act = Ly.activation != 0;
+            const bool div = Ly.post_div_sqrt2 != 0;
+            const float sqrt2 = 1.41421356237309515f;
+            if (q < ntw) {
+                const int f = 16 * (u0 + q) + 4 * jj;
+                const float4 bb = *reinterpret_cast<const float4 *>(Ly.bias + f);
+                float v[8] = {r0[0] + bb.x, r0[1] + bb.y, r0[2] + bb.z, r0[3] + bb.w,
+                              r1[0] + bb.x, r1[1] + bb.y, r1[2] + bb.z, r1[3] + bb.w};
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (act) v[i] = softplus100(v[i]);
+                    if (div) v[i] = __fdiv_rn(v[i], sqrt2);
+                }
+                float *dst = X + (f >> 2) * kGroupFloats8;
+                *reinterpret_cast<float4 *>(dst + p4 * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4 *>(dst + (p4 + 4) * 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+            if (li == 0) {
+                for (int i = tid; i < emb_groups16 * kGroupFloats8; i += kThreadsSdf) EMB[i] = __fdiv_rn(EMB[i], sqrt2);
+            }
+            __syncthreads();
+        }
+
+        const hm_mlp_layer &last = net.layer[net.n_layers - 1];
+        if (out_cols != 1) {
+            const int od = last.out_dim;
+            for (int i = tid; i < cnt * od; i += kThreadsSdf) {
+                const int p = i / od, f = i - p * od;
+                float v = X[(f >> 2) * kGroupFloats8 + p * 4 + (f & 3)];
+                if (f == 0) v = sdf_clamp(v, net.beta);
+                out[(base + p) * out_stride + f] = v;
+            }
+        }
+    }
+}
+
+// small batches: one launch, the tile size is chosen on the device from the live point count
+template <int FRAC>
+__global__ __launch_bounds__(kThreadsSdf, 1) void sdf_fwd_small_kernel(HmLevels lv, SdfNet net,
+                                                                        const float *__restrict__ x, int64_t n,
+                                                                        const float *__restrict__ table,
+                                                                        const float *__restrict__ Bf,
+                                                                        float *__restrict__ out, int64_t out_stride,
+                                                                        int out_cols, const int32_t *__restrict__ n_dev,
+                                                                        int64_t run_min, int64_t run_max, int64_t m8_max) {
+    extern __shared__ __align__(16) float lds[];
+    if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));
+    if (n < run_min || n > run_max) return;
+    if (n <= m8_max)
+        sdf_m8_body<FRAC>(lv, net, x, n, table, Bf, out, out_stride, out_cols, lds);
+    else
+        sdf_m16_body<FRAC>(lv, net, x, n, table, Bf, out, out_stride, out_cols, lds);
+}
+
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 }  // namespace
@@ -508,7 +793,8 @@ int hm_sdf_fwd(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *x,
     HM_CHECK_ARG(n >= 0, "hm_sdf_fwd: n < 0");
     HM_CHECK_ARG(frac_mode == HM_FRAC_REFERENCE || frac_mode == HM_FRAC_TRILINEAR, "hm_sdf_fwd: bad frac_mode");
     HM_CHECK_ARG(mlp->n_layers >= 1 && mlp->n_layers <= HM_MAX_LAYERS, "hm_sdf_fwd: n_layers out of range");
-    HM_CHECK_ARG(tile_points == 0 || tile_points == 16 || tile_points == 64, "hm_sdf_fwd: tile_points must be 0, 16 or 64");
+    HM_CHECK_ARG(tile_points == 0 || tile_points == 8 || tile_points == 16 || tile_points == 64,
+                 "hm_sdf_fwd: tile_points must be 0, 8, 16 or 64");
     const HmLevels &lv = desc->lv;
     SdfNet net;
     net.n_layers = mlp->n_layers;
@@ -549,7 +835,8 @@ int hm_sdf_fwd(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *x,
     const hm_mlp_layer &last = mlp->layer[mlp->n_layers - 1];
     HM_CHECK_ARG(out_cols == 1 || out_cols == last.out_dim, "hm_sdf_fwd: out_cols must be 1 or the last layer's out_dim");
     HM_CHECK_ARG(out_stride >= out_cols, "hm_sdf_fwd: out_stride < out_cols");
-    HM_CHECK_ARG(tile_points != 16 || have16, "hm_sdf_fwd: tile_points 16 needs w_packed_m16 in every layer");
+    HM_CHECK_ARG((tile_points != 16 && tile_points != 8) || have16,
+                 "hm_sdf_fwd: tile_points 8 / 16 need w_packed_m16 in every layer");
     if (n == 0) return HM_OK;
     HM_CHECK_ARG(x && table && B_fourier && out, "hm_sdf_fwd: NULL pointer");
     // small batches: 16-point tiles spread the call over the whole chip (see sdf_fwd_m16_kernel).
@@ -559,11 +846,15 @@ int hm_sdf_fwd(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *x,
     const int64_t kBig = (int64_t)1 << 62;
     bool run16 = false, run64 = false;
     int64_t lo16 = 0, hi16 = kBig, lo64 = 0, hi64 = kBig;
-    if (tile_points == 16) run16 = true;
+    // 8-point tiles below kTiny live points (one tile per CU), 16-point tiles up to kSmall, 64 above
+    constexpr int64_t kTiny = 2048;
+    int64_t m8_max = 0;
+    if (tile_points == 8) { run16 = true; m8_max = kBig; }
+    else if (tile_points == 16) run16 = true;
     else if (tile_points == 64 || !have16) run64 = true;
-    else if (!n_dev) { run16 = n <= kSmall; run64 = !run16; }
-    else if (n <= kSmall) run16 = true;
-    else { run16 = run64 = true; hi16 = kSmall; lo64 = kSmall + 1; }
+    else if (!n_dev) { run16 = n <= kSmall; run64 = !run16; m8_max = kTiny; }
+    else if (n <= kSmall) { run16 = true; m8_max = kTiny; }
+    else { run16 = run64 = true; hi16 = kSmall; lo64 = kSmall + 1; m8_max = kTiny; }
     static thread_local bool attr_done = false;
     if (!attr_done) {  // opt in to >64 KB dynamic LDS once (not a stream operation)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sdf_fwd_kernel<HM_FRAC_REFERENCE>),
@@ -576,20 +867,24 @@ int hm_sdf_fwd(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *x,
     }
     if (run16) {
         const size_t lds = sizeof(float) * ((size_t)(net.x_groups + emb_b16 * 4) * kGroupFloats16 + kPts16 * 4 +
-                                            kWaves * kPts16);
+                                            kWaves * kPts16);   // (the 8-point layout needs half of this)
         HM_CHECK_ARG(lds <= 64 * 1024, "hm_sdf_fwd: network does not fit the 16-point LDS tile");
         const int64_t nmax = n < hi16 ? n : hi16;
-        const int64_t tiles = (nmax + kPts16 - 1) / kPts16;
-        const int64_t cap = max_workgroups > 0 ? max_workgroups : 256;  // one resident workgroup per CU (147 VGPRs)
+        int64_t tiles = m8_max >= nmax ? 0 : (nmax + kPts16 - 1) / kPts16;
+        if (m8_max > 0) {
+            const int64_t n8 = nmax < m8_max ? nmax : m8_max;
+            tiles = max(tiles, (n8 + kPts8 - 1) / kPts8);
+        }
+        const int64_t cap = max_workgroups > 0 ? max_workgroups : 256;  // one resident workgroup per CU
         const int64_t grid = tiles < cap ? tiles : cap;
         if (frac_mode == HM_FRAC_REFERENCE)
-            hipLaunchKernelGGL(sdf_fwd_m16_kernel<HM_FRAC_REFERENCE>, dim3((unsigned)grid), dim3(kThreadsSdf), lds,
+            hipLaunchKernelGGL(sdf_fwd_small_kernel<HM_FRAC_REFERENCE>, dim3((unsigned)grid), dim3(kThreadsSdf), lds,
                                as_stream(stream), lv, net, x, n, table, B_fourier, out, out_stride, out_cols, n_dev,
-                               lo16, hi16);
+                               lo16, hi16, m8_max);
         else
-            hipLaunchKernelGGL(sdf_fwd_m16_kernel<HM_FRAC_TRILINEAR>, dim3((unsigned)grid), dim3(kThreadsSdf), lds,
+            hipLaunchKernelGGL(sdf_fwd_small_kernel<HM_FRAC_TRILINEAR>, dim3((unsigned)grid), dim3(kThreadsSdf), lds,
                                as_stream(stream), lv, net, x, n, table, B_fourier, out, out_stride, out_cols, n_dev,
-                               lo16, hi16);
+                               lo16, hi16, m8_max);
     }
     if (run64) {
         const size_t lds = sizeof(float) * ((size_t)(net.x_groups + net.emb_groups) * kGroupFloats + kPts * 4 +
