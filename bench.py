@@ -231,6 +231,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / cpu_baseline sections")
     ap.add_argument("--no-graph", action="store_true",
                     help="eager reference-structured step (dynamic shapes) instead of the HIP-graph captured step")
+    ap.add_argument("--torch-adam", action="store_true",
+                    help="torch.nn.utils.clip_grad_norm_ + torch.optim.Adam instead of the fused training.optim.ClipAdam")
     ap.add_argument("--gather-log2n", type=int, default=22)
     ap.add_argument("--only", choices=["gather", "gather_bwd", "mlp"], default=None,
                     help="profiling helper: run just one kernel section on cuda:0 and print its object")
@@ -269,7 +271,11 @@ def main():
         model.implicit_network.use_fused_mlp_grad = False
     loss_fn = IDRLoss(eikonal_weight=0.1, mask_weight=100.0, alpha=50.0)
     # dense Adam over ALL parameters incl. the hash table (reference: idr_train.py:127-128)
-    opt = torch.optim.Adam(model.parameters(), lr=1.0e-4, capturable=not args.no_graph)
+    if args.torch_adam:
+        opt = torch.optim.Adam(model.parameters(), lr=1.0e-4, capturable=not args.no_graph)
+    else:   # same update, clip_grad_norm_(1.0) + Adam in three launches (csrc/hm_optim.hip)
+        from hashmodnffbanks_idr_amd.training.optim import ClipAdam
+        opt = ClipAdam(model.parameters(), lr=1.0e-4, max_norm=1.0)
     reducer = parallel.GradAllReducer(model.parameters()) if world > 1 else None
     inp, gt = synthetic_batch(1234 + rank, args.rays, device)
     torch.manual_seed(100 + rank)  # per-rank eikonal points / step fractions

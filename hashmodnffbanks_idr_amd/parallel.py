@@ -108,6 +108,7 @@ def train_step(model, loss_fn, optimizer, model_input, ground_truth, reducer=Non
     loss_out["loss"].backward()
     if reducer is not None:
         reducer()
-    torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=max_norm)
+    if not getattr(optimizer, "fused_clip", False):   # training.optim.ClipAdam clips inside its own pass
+        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=max_norm)
     optimizer.step()
     return out, loss_out

@@ -31,8 +31,8 @@ class GraphedTrainStep:
         self.static = None
         self.out = self.loss_out = None
         for grp in optimizer.param_groups:
-            if use_graph and not grp.get("capturable", False):
-                raise ValueError("GraphedTrainStep needs torch.optim.Adam(..., capturable=True)")
+            if use_graph and not (grp.get("capturable", False) or getattr(optimizer, "fused_clip", False)):
+                raise ValueError("GraphedTrainStep needs training.optim.ClipAdam or torch.optim.Adam(..., capturable=True)")
 
     # -- pieces -------------------------------------------------------------------------------
     def _draws(self, n_rays, dev):
@@ -63,7 +63,8 @@ class GraphedTrainStep:
         return out, lo
 
     def _update(self):
-        torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=self.max_norm)
+        if not getattr(self.opt, "fused_clip", False):   # training.optim.ClipAdam clips inside its own pass
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=self.max_norm)
         self.opt.step()
 
     def _eager_iteration(self):

@@ -1,0 +1,95 @@
+"""clip_grad_norm_ + Adam as three HIP launches (csrc/hm_optim.hip) behind the torch.optim interface.
+
+Reference iteration tail (training/idr_train.py:128,306-309):
+    torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=1.0);  self.optimizer.step()
+with ``torch.optim.Adam(model.parameters(), lr)``.  ``ClipAdam.step()`` does both (``max_norm=None`` turns the
+clipping off and leaves plain Adam); hyper-parameters, update formulas and the ``state_dict`` layout
+(``step`` / ``exp_avg`` / ``exp_avg_sq`` per parameter) are torch.optim.Adam's, so optimizer checkpoints
+(``OptimizerParameters/*.pth``, idr_train.py:189-194) load both ways.  Everything stays on the device: the step
+counter is a device int64, so ``step()`` can sit inside a captured HIP graph.
+"""
+import ctypes as C
+
+import torch
+
+from .. import _lib
+from .._lib import check, lib, require_gpu
+
+
+class ClipAdam(torch.optim.Optimizer):
+    fused_clip = True   # GraphedTrainStep / parallel.train_step: do not call clip_grad_norm_ separately
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0):
+        if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
+            raise ValueError("ClipAdam: invalid hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps))
+        self.max_norm = max_norm
+        self._dev_state = {}     # device -> (per-parameter step counters int64[n_params], scratch float[2])
+        self.last_grad_norm = None   # device scalar: total gradient norm before clipping (of the last step)
+
+    def _device_state(self, dev):
+        st = self._dev_state.get(dev)
+        if st is None:
+            n = sum(len(g["params"]) for g in self.param_groups)
+            st = (torch.zeros(n, dtype=torch.int64, device=dev), torch.zeros(2, dtype=torch.float32, device=dev))
+            self._dev_state[dev] = st
+        return st
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        if len(self.param_groups) != 1:
+            # the global gradient norm spans all groups; one hyper-parameter set keeps it a single pass
+            raise NotImplementedError("ClipAdam supports one parameter group (as the reference runner uses)")
+        grp = self.param_groups[0]
+        plist = [(k, p) for k, p in enumerate(grp["params"]) if p.grad is not None]
+        if not plist:
+            return loss
+        dev = plist[0][1].device
+        steps, scratch = self._device_state(dev)
+        table = (_lib.AdamTensor * len(plist))()
+        for i, (k, p) in enumerate(plist):
+            require_gpu(p, p.grad)
+            if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or p.device != dev:
+                raise TypeError("ClipAdam: fp32 parameters on one device only")
+            if not p.is_contiguous():
+                raise ValueError("ClipAdam: parameters must be contiguous")
+            if not p.grad.is_contiguous():
+                p.grad = p.grad.contiguous()
+            st = self.state[p]
+            if not st:
+                st["step"] = None    # materialised by state_dict(); the live counters sit in one device array
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            table[i] = _lib.AdamTensor(p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(),
+                                       st["exp_avg_sq"].data_ptr(), steps.data_ptr() + 8 * k, p.numel())
+        b1, b2 = grp["betas"]
+        check(lib().hm_adam_step(C.cast(table, C.c_void_p), len(plist), float(grp["lr"]), float(b1), float(b2),
+                                 float(grp["eps"]), float(self.max_norm) if self.max_norm else 0.0,
+                                 C.c_void_p(scratch.data_ptr()), _lib.stream_ptr(plist[0][1])))
+        self.last_grad_norm = scratch[1]
+        return loss
+
+    # -- torch.optim.Adam-compatible checkpoints ---------------------------------------------------------
+    def state_dict(self):
+        for grp in self.param_groups:
+            for k, p in enumerate(grp["params"]):
+                st = self.state.get(p)
+                if st:
+                    dev_state = self._dev_state.get(p.device)
+                    st["step"] = (dev_state[0][k].to(torch.float32).clone() if dev_state is not None
+                                  else torch.zeros((), dtype=torch.float32))
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._dev_state = {}
+        for grp in self.param_groups:
+            for k, p in enumerate(grp["params"]):
+                st = self.state.get(p)
+                if st and st.get("step") is not None:
+                    steps, _ = self._device_state(p.device)
+                    steps[k] = int(float(st["step"]))

@@ -207,6 +207,22 @@ HM_API int hm_softplus(int order, const float *z, const float *gy, const float *
 /* out[n] = sum over rows of x[M,N] (row stride ld) - the bias gradient of an nn.Linear.          */
 HM_API int hm_colsum(const float *x, int64_t M, int64_t N, int64_t ld, float *out, void *stream);
 
+/* ---- optimizer tail of the training iteration ---------------------------------------------------
+ * torch.nn.utils.clip_grad_norm_(parameters, max_norm) followed by torch.optim.Adam.step()
+ * (training/idr_train.py:128,306-309; amsgrad / weight decay off as in the reference) over all tensors in
+ * three launches.  In place: grad *= clip coefficient, exp_avg, exp_avg_sq, param.  max_norm <= 0 skips the
+ * clipping.  Every tensor's step counter is incremented by the call (the bias corrections use the incremented
+ * value); tensors left out of a call (no gradient) keep theirs, as in torch.  scratch_dev: 2 device floats; scratch_dev[1] receives the total gradient norm
+ * (before clipping) when max_norm > 0.  Sync-free and graph-capturable.                              */
+#define HM_ADAM_MAX_TENSORS 64
+typedef struct hm_adam_tensor {
+    float *param, *grad, *exp_avg, *exp_avg_sq;  /* device, fp32, contiguous, same numel */
+    int64_t *step;                               /* device iteration counter of THIS tensor (torch: state['step']) */
+    int64_t numel;
+} hm_adam_tensor;
+HM_API int hm_adam_step(const hm_adam_tensor *tensors, int n_tensors, float lr, float beta1, float beta2, float eps,
+                        float max_norm, float *scratch_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
