@@ -36,6 +36,7 @@ SIGNATURES = {
     "hm_softplus": (_int, [_int, _p, _p, _p, _p, _p, _i64, C.c_float, C.c_float, _p]),
     "hm_colsum": (_int, [_p, _i64, _i64, _i64, _p, _p]),
     "hm_adam_step": (_int, [_p, _int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _p, _p]),
+    "hm_gemm_f32_ep": (_int, [_int, _int, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _p]),
     "hm_gemm_f32": (_int, [_int, _int, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _int, _p]),
 }
 
@@ -44,6 +45,13 @@ class MlpLayer(C.Structure):
     _fields_ = [("w_packed", C.c_void_p), ("bias", C.c_void_p), ("out_dim", C.c_int32), ("n_tiles", C.c_int32),
                 ("seg_octets", C.c_int32 * 2), ("seg_src", C.c_int32 * 2), ("activation", C.c_int32),
                 ("post_div_sqrt2", C.c_int32), ("w_packed_m16", C.c_void_p), ("seg_blocks16", C.c_int32 * 2)]
+
+
+class GemmEpilogue(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("nz", C.c_int32), ("scale", C.c_float), ("beta", C.c_float),
+                ("threshold", C.c_float), ("z", C.c_void_p), ("ldz", C.c_int64), ("g", C.c_void_p), ("ldg", C.c_int64),
+                ("out1", C.c_void_p), ("ld1", C.c_int64), ("out2", C.c_void_p), ("ld2", C.c_int64),
+                ("out3", C.c_void_p), ("ld3", C.c_int64)]
 
 
 class AdamTensor(C.Structure):

@@ -57,6 +57,29 @@ static inline void hm_zero_u32_async(void *p, int64_t n_words, hipStream_t st) {
                            static_cast<uint32_t *>(p), n_words);
 }
 
+// nn.Softplus(beta, threshold) and its derivatives with torch's formulas (shared by hm_elem.hip and the GEMM epilogues)
+struct SpDeriv {
+    float s1, s2;
+};
+__device__ __forceinline__ float hm_softplus_fwd(float z, float beta, float thr) {
+    return z * beta > thr ? z : log1pf(expf(z * beta)) / beta;
+}
+// s1 = d softplus/dz = e/(e+1), s2 = d^2 softplus/dz^2 = beta*e/(e+1)^2 (no cancellation in 1 - s1), e = exp(beta z)
+__device__ __forceinline__ SpDeriv hm_sp_deriv(float z, float beta, float thr) {
+    SpDeriv d;
+    const float bz = z * beta;
+    if (bz > thr) {
+        d.s1 = 1.0f;
+        d.s2 = 0.0f;
+    } else {
+        const float e = expf(bz);
+        const float ep1 = e + 1.0f;
+        d.s1 = e / ep1;
+        d.s2 = beta * e / (ep1 * ep1);
+    }
+    return d;
+}
+
 // hash of one voxel corner: reference hashGridEmbedding.py:32-40 restated in uint32
 // (primes 1, 3, 2654435761; xor fold; unsigned modulo by the level's row count).
 __device__ __forceinline__ uint32_t hm_mod_rows(uint32_t h, uint32_t rows, uint32_t magic) {

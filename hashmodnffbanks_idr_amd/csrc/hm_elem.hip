@@ -11,38 +11,19 @@ namespace {
 
 constexpr int kET = 256;
 
-struct SpDeriv {
-    float s1, s2;
-};
-// s1 = d softplus/dz, s2 = d^2 softplus/dz^2 with torch's formulas (exp(beta z)/(exp(beta z)+1))
-__device__ __forceinline__ SpDeriv sp_deriv(float z, float beta, float thr) {
-    SpDeriv d;
-    const float bz = z * beta;
-    if (bz > thr) {
-        d.s1 = 1.0f;
-        d.s2 = 0.0f;
-    } else {
-        const float e = expf(bz);
-        const float ep1 = e + 1.0f;
-        d.s1 = e / ep1;
-        d.s2 = beta * e / (ep1 * ep1);  // = beta*s1*(1-s1) without the cancellation in (1 - s1)
-    }
-    return d;
-}
-
 __global__ __launch_bounds__(kET) void softplus_fwd_kernel(const float *__restrict__ z, float *__restrict__ y,
                                                            int64_t n, float beta, float thr) {
     const int64_t i = ((int64_t)blockIdx.x * kET + threadIdx.x) * 4;
     if (i + 3 < n) {
         const float4 v = *reinterpret_cast<const float4 *>(z + i);
         float4 o;
-        o.x = v.x * beta > thr ? v.x : log1pf(expf(v.x * beta)) / beta;
-        o.y = v.y * beta > thr ? v.y : log1pf(expf(v.y * beta)) / beta;
-        o.z = v.z * beta > thr ? v.z : log1pf(expf(v.z * beta)) / beta;
-        o.w = v.w * beta > thr ? v.w : log1pf(expf(v.w * beta)) / beta;
+        o.x = hm_softplus_fwd(v.x, beta, thr);
+        o.y = hm_softplus_fwd(v.y, beta, thr);
+        o.z = hm_softplus_fwd(v.z, beta, thr);
+        o.w = hm_softplus_fwd(v.w, beta, thr);
         *reinterpret_cast<float4 *>(y + i) = o;
     } else {
-        for (int64_t k = i; k < n; ++k) y[k] = z[k] * beta > thr ? z[k] : log1pf(expf(z[k] * beta)) / beta;
+        for (int64_t k = i; k < n; ++k) y[k] = hm_softplus_fwd(z[k], beta, thr);
     }
 }
 
@@ -54,13 +35,13 @@ __global__ __launch_bounds__(kET) void softplus_bwd_kernel(const float *__restri
         const float4 v = *reinterpret_cast<const float4 *>(z + i);
         const float4 g = *reinterpret_cast<const float4 *>(gy + i);
         float4 o;
-        o.x = g.x * sp_deriv(v.x, beta, thr).s1;
-        o.y = g.y * sp_deriv(v.y, beta, thr).s1;
-        o.z = g.z * sp_deriv(v.z, beta, thr).s1;
-        o.w = g.w * sp_deriv(v.w, beta, thr).s1;
+        o.x = g.x * hm_sp_deriv(v.x, beta, thr).s1;
+        o.y = g.y * hm_sp_deriv(v.y, beta, thr).s1;
+        o.z = g.z * hm_sp_deriv(v.z, beta, thr).s1;
+        o.w = g.w * hm_sp_deriv(v.w, beta, thr).s1;
         *reinterpret_cast<float4 *>(gz + i) = o;
     } else {
-        for (int64_t k = i; k < n; ++k) gz[k] = gy[k] * sp_deriv(z[k], beta, thr).s1;
+        for (int64_t k = i; k < n; ++k) gz[k] = gy[k] * hm_sp_deriv(z[k], beta, thr).s1;
     }
 }
 
@@ -75,14 +56,14 @@ __global__ __launch_bounds__(kET) void softplus_bwd_bwd_kernel(const float *__re
         const float4 v = *reinterpret_cast<const float4 *>(z + i);
         const float4 g = *reinterpret_cast<const float4 *>(gy + i);
         const float4 q = *reinterpret_cast<const float4 *>(gg + i);
-        const SpDeriv a = sp_deriv(v.x, beta, thr), b = sp_deriv(v.y, beta, thr), c = sp_deriv(v.z, beta, thr),
-                      d = sp_deriv(v.w, beta, thr);
+        const SpDeriv a = hm_sp_deriv(v.x, beta, thr), b = hm_sp_deriv(v.y, beta, thr), c = hm_sp_deriv(v.z, beta, thr),
+                      d = hm_sp_deriv(v.w, beta, thr);
         *reinterpret_cast<float4 *>(d_gy + i) = make_float4(q.x * a.s1, q.y * b.s1, q.z * c.s1, q.w * d.s1);
         *reinterpret_cast<float4 *>(d_z + i) =
             make_float4(q.x * g.x * a.s2, q.y * g.y * b.s2, q.z * g.z * c.s2, q.w * g.w * d.s2);
     } else {
         for (int64_t k = i; k < n; ++k) {
-            const SpDeriv a = sp_deriv(z[k], beta, thr);
+            const SpDeriv a = hm_sp_deriv(z[k], beta, thr);
             d_gy[k] = gg[k] * a.s1;
             d_z[k] = gg[k] * gy[k] * a.s2;
         }
@@ -96,9 +77,16 @@ __global__ __launch_bounds__(kET) void colsum_kernel(const float *__restrict__ x
     if (n >= N) return;
     const int64_t m0 = (int64_t)blockIdx.y * rows_per_block;
     const int64_t m1 = min(M, m0 + rows_per_block);
-    float acc = 0.0f;
-    for (int64_t m = m0; m < m1; ++m) acc += x[m * ld + n];
-    atomicAdd(out + n, acc);
+    // eight independent row streams per thread keep the loads of a slab in flight together
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
+    const float *p = x + m0 * ld + n;
+    int64_t m = m0;
+    for (; m + 8 <= m1; m += 8, p += 8 * ld) {
+        a0 += p[0]; a1 += p[ld]; a2 += p[2 * ld]; a3 += p[3 * ld];
+        a4 += p[4 * ld]; a5 += p[5 * ld]; a6 += p[6 * ld]; a7 += p[7 * ld];
+    }
+    for (; m < m1; ++m, p += ld) a0 += *p;
+    atomicAdd(out + n, ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7)));
 }
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
@@ -140,7 +128,7 @@ int hm_colsum(const float *x, int64_t M, int64_t N, int64_t ld, float *out, void
     hm_zero_u32_async(out, N, st);
     if (M == 0) return HM_OK;
     HM_CHECK_ARG(x != nullptr, "hm_colsum: x is NULL");
-    int rows = 64;
+    int rows = 32;
     int64_t slabs = (M + rows - 1) / rows;
     if (slabs > 65535) { rows = (int)((M + 65534) / 65535); slabs = (M + rows - 1) / rows; }
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((N + kET - 1) / kET), (unsigned)slabs), dim3(kET), 0, st, x, M, N,

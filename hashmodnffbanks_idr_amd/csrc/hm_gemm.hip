@@ -30,6 +30,7 @@ struct GemmArgs {
     int32_t k_chunk;  // K range handled by one blockIdx.z
     int32_t atomic;   // accumulate with atomics (split-K, or beta = 1)
     int32_t vecA, vecB;  // operand may be fetched with aligned 16-B loads
+    hm_gemm_epilogue ep;  // fused elementwise epilogue (mode HM_EPI_NONE = plain store)
 };
 
 // LDS image of an operand tile: S[kg][row][4] (kg = k/4) with the row XOR-swizzled by kg so that both
@@ -99,8 +100,11 @@ __device__ __forceinline__ void store_tile(float *__restrict__ S, bool kcontig, 
 // KS = intra-workgroup K split: 4*KS waves, wave group g multiplies octets [g*BK/8/KS, (g+1)*BK/8/KS) of every
 // stage, partial tiles are summed through LDS at the end.  Two waves per SIMD keep the matrix pipe busy
 // while the next stage's loads are in flight even when the grid has only one workgroup per CU.
-template <int TM, int TN, int BK, int KS, bool VA, bool VB>
-__global__ __launch_bounds__(256 * KS) void gemm_f32_kernel(GemmArgs g) {
+// EP: compiled with the fused epilogues (kept out of the plain instantiation: its extra registers would drop the
+// 64x64 configuration from two resident workgroups per CU to one).  The 8-wave configuration is held to 128 VGPRs
+// (4 waves per SIMD = two workgroups per CU).
+template <int TM, int TN, int BK, int KS, bool VA, bool VB, bool EP>
+__global__ __launch_bounds__(256 * KS, (KS == 2 ? 4 : 1)) void gemm_f32_kernel(GemmArgs g) {
     constexpr int BM = 64 * TM, BN = 64 * TN, NT = 256 * KS;
     __shared__ __align__(16) float As[BK * BM];
     __shared__ __align__(16) float Bs[BK * BN];
@@ -185,16 +189,60 @@ __global__ __launch_bounds__(256 * KS) void gemm_f32_kernel(GemmArgs g) {
             const int n = n0 + wn * 32 * TN + tn * 32 + j;
             if (n >= g.N) continue;
             const float bv = add_bias ? g.bias[n] : 0.0f;
+            const int mode = EP ? g.ep.mode : (int)HM_EPI_NONE;
+            const int mrow0 = m0 + wm * 32 * TM + tm * 32 + 4 * h;
+            // epilogue operands first, all 16 (+16) loads in flight together on clamped addresses: a load under
+            // a per-row guard would be waited for one at a time
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 32 * TM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            for (int half = 0; half < 2; ++half) {
+            float zv[8], gv[8];
+            if (mode >= HM_EPI_S1MUL) {
+                const int nc = mode == HM_EPI_S1MUL ? min(n, g.ep.nz - 1) : n;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int r = 8 * half + q;
+                    const int mc = min(mrow0 + (r & 3) + 8 * (r >> 2), g.M - 1);
+                    zv[q] = g.ep.z[(int64_t)mc * g.ep.ldz + nc];
+                }
+                if (g.ep.g) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int r = 8 * half + q;
+                        const int mc = min(mrow0 + (r & 3) + 8 * (r >> 2), g.M - 1);
+                        gv[q] = g.ep.g[(int64_t)mc * g.ep.ldg + nc];
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) gv[q] = 0.0f;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r = 8 * half + q;
+                const int m = mrow0 + (r & 3) + 8 * (r >> 2);
                 if (m >= g.M) continue;
-                const float v = acc[tm][tn][r] + bv;
-                float *dst = g.C + (int64_t)m * g.ldc + n;
-                if (g.atomic)
-                    atomicAdd(dst, v);
-                else
-                    *dst = v;
+                float v = acc[tm][tn][r] + bv;
+                if (mode != HM_EPI_NONE) v *= g.ep.scale;
+                if (g.C) {
+                    float *dst = g.C + (int64_t)m * g.ldc + n;
+                    if (g.atomic)
+                        atomicAdd(dst, v);
+                    else
+                        *dst = v;
+                }
+                if (mode == HM_EPI_SOFTPLUS) {
+                    g.ep.out1[(int64_t)m * g.ep.ld1 + n] = hm_softplus_fwd(v, g.ep.beta, g.ep.threshold);
+                } else if (mode == HM_EPI_S1MUL) {
+                    if (n < g.ep.nz)
+                        g.ep.out1[(int64_t)m * g.ep.ld1 + n] =
+                            v * hm_sp_deriv(zv[q], g.ep.beta, g.ep.threshold).s1 + gv[q];
+                } else if (mode == HM_EPI_ADJOINT) {
+                    const SpDeriv d = hm_sp_deriv(zv[q], g.ep.beta, g.ep.threshold);
+                    g.ep.out1[(int64_t)m * g.ep.ld1 + n] = v * d.s1;
+                    g.ep.out2[(int64_t)m * g.ep.ld2 + n] = v * gv[q] * d.s2;
+                    if (g.ep.out3) g.ep.out3[(int64_t)m * g.ep.ld3 + n] = gv[q] * d.s1;
+                }
+            }
             }
         }
 }
@@ -212,18 +260,32 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 
 }  // namespace
 
-extern "C" {
-
-int hm_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const float *A, int64_t lda,
-                const float *B, int64_t ldb, const float *bias, float *C, int64_t ldc, int accumulate,
-                void *stream) {
+static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K, const float *A, int64_t lda,
+                     const float *B, int64_t ldb, const float *bias, float *C, int64_t ldc, int accumulate,
+                     const hm_gemm_epilogue *ep, void *stream) {
     HM_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "hm_gemm_f32: negative dimension");
     HM_CHECK_ARG(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "hm_gemm_f32: dimension too large");
     if (M == 0 || N == 0) return HM_OK;
-    HM_CHECK_ARG(C != nullptr, "hm_gemm_f32: C is NULL");
+    HM_CHECK_ARG(C != nullptr || (ep && ep->mode != HM_EPI_NONE), "hm_gemm_f32: C is NULL");
     HM_CHECK_ARG(K == 0 || (A && B), "hm_gemm_f32: NULL operand");
-    HM_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, "hm_gemm_f32: leading dimension");
+    HM_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && (!C || ldc >= N), "hm_gemm_f32: leading dimension");
     GemmArgs g;
+    g.ep = hm_gemm_epilogue{};
+    if (ep && ep->mode != HM_EPI_NONE) {
+        HM_CHECK_ARG(!accumulate, "hm_gemm_f32_ep: an epilogue cannot be combined with accumulate");
+        HM_CHECK_ARG(ep->mode >= HM_EPI_SOFTPLUS && ep->mode <= HM_EPI_ADJOINT, "hm_gemm_f32_ep: unknown epilogue mode");
+        HM_CHECK_ARG(ep->out1 && ep->ld1 >= (ep->mode == HM_EPI_S1MUL ? ep->nz : N), "hm_gemm_f32_ep: out1");
+        if (ep->mode != HM_EPI_SOFTPLUS) {
+            const int64_t nzc = ep->mode == HM_EPI_S1MUL ? ep->nz : N;
+            HM_CHECK_ARG(ep->z && ep->ldz >= nzc, "hm_gemm_f32_ep: z");
+            HM_CHECK_ARG(ep->mode != HM_EPI_S1MUL || (ep->nz >= 1 && ep->nz <= N), "hm_gemm_f32_ep: nz out of range");
+            HM_CHECK_ARG(!ep->g || ep->ldg >= nzc, "hm_gemm_f32_ep: g");
+        }
+        if (ep->mode == HM_EPI_ADJOINT) {
+            HM_CHECK_ARG(ep->g && ep->out2 && ep->ld2 >= N && (!ep->out3 || ep->ld3 >= N), "hm_gemm_f32_ep: ADJOINT operands");
+        }
+        g.ep = *ep;
+    }
     g.A = A; g.B = B; g.bias = bias; g.C = C;
     g.M = (int)M; g.N = (int)N; g.K = (int)K;
     g.transA = transA; g.transB = transB;
@@ -235,13 +297,14 @@ int hm_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const f
     g.vecB = (b_kc && K % 4 == 0 && ldb % 4 == 0 && (reinterpret_cast<uintptr_t>(B) & 15u) == 0) ? 1 : 0;
     // tile choice: big tiles only when they still fill the chip
     const int64_t t128 = ((M + 127) / 128) * ((N + 127) / 128);
-    const bool big = t128 >= 256;
-    const int64_t bm = big ? 128 : 64, bn = big ? 128 : 64;
     static const int small_cfg = [] { const char *e = getenv("HM_GEMM_CFG"); return e ? atoi(e) : 0; }();
-    const int64_t kBK = big ? 32 : (small_cfg == 1 || small_cfg == 2 ? 64 : 128);
+    const bool big = t128 >= 256 || small_cfg == 5;
+    // experiment configs (HM_GEMM_CFG): 3 = 128x64 tile, 4 = 64x128 tile (BK 64, 4 waves)
+    const int64_t bm = big ? 128 : (small_cfg == 3 ? 128 : 64), bn = big ? 128 : (small_cfg == 4 ? 128 : 64);
+    const int64_t kBK = big ? 32 : (small_cfg >= 1 && small_cfg <= 4 ? 64 : 128);
     const int64_t tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
     int64_t split = 1;
-    if (tiles < 256 && K >= 256) {
+    if (tiles < 256 && K >= 256 && g.ep.mode == HM_EPI_NONE) {   // (a nonlinear epilogue needs the full sum)
         split = (512 + tiles - 1) / tiles;
         const int64_t max_split = K / 128;
         if (split > max_split) split = max_split;
@@ -262,14 +325,23 @@ int hm_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const f
     HM_CHECK_ARG(grid.y <= 65535u && grid.z <= 65535u, "hm_gemm_f32: N or split too large for one launch");
 #define HM_GEMM_LAUNCH(TM_, TN_, BK_, KS_)                                                                      \
     do {                                                                                                        \
-        if (g.vecA && g.vecB)                                                                                   \
-            hipLaunchKernelGGL((gemm_f32_kernel<TM_, TN_, BK_, KS_, true, true>), grid, dim3(256 * KS_), 0, st, g); \
+        if (g.ep.mode != HM_EPI_NONE) {                                                                         \
+            if (g.vecA && g.vecB)                                                                               \
+                hipLaunchKernelGGL((gemm_f32_kernel<TM_, TN_, BK_, KS_, true, true, true>), grid, dim3(256 * KS_), 0, st, g); \
+            else if (g.vecA)                                                                                    \
+                hipLaunchKernelGGL((gemm_f32_kernel<TM_, TN_, BK_, KS_, true, false, true>), grid, dim3(256 * KS_), 0, st, g); \
+            else if (g.vecB)                                                                                    \
+                hipLaunchKernelGGL((gemm_f32_kernel<TM_, TN_, BK_, KS_, false, true, true>), grid, dim3(256 * KS_), 0, st, g); \
+            else                                                                                                \
+                hipLaunchKernelGGL((gemm_f32_kernel<TM_, TN_, BK_, KS_, false, false, true>), grid, dim3(256 * KS_), 0, st, g); \
+        } else if (g.vecA && g.vecB)                                                                            \
+            hipLaunchKernelGGL((gemm_f32_kernel<TM_, TN_, BK_, KS_, true, true, false>), grid, dim3(256 * KS_), 0, st, g); \
         else if (g.vecA)                                                                                        \
-            hipLaunchKernelGGL((gemm_f32_kernel<TM_, TN_, BK_, KS_, true, false>), grid, dim3(256 * KS_), 0, st, g); \
+            hipLaunchKernelGGL((gemm_f32_kernel<TM_, TN_, BK_, KS_, true, false, false>), grid, dim3(256 * KS_), 0, st, g); \
         else if (g.vecB)                                                                                        \
-            hipLaunchKernelGGL((gemm_f32_kernel<TM_, TN_, BK_, KS_, false, true>), grid, dim3(256 * KS_), 0, st, g); \
+            hipLaunchKernelGGL((gemm_f32_kernel<TM_, TN_, BK_, KS_, false, true, false>), grid, dim3(256 * KS_), 0, st, g); \
         else                                                                                                    \
-            hipLaunchKernelGGL((gemm_f32_kernel<TM_, TN_, BK_, KS_, false, false>), grid, dim3(256 * KS_), 0, st, g); \
+            hipLaunchKernelGGL((gemm_f32_kernel<TM_, TN_, BK_, KS_, false, false, false>), grid, dim3(256 * KS_), 0, st, g); \
     } while (0)
     hipStream_t st = as_stream(stream);
     if (big)
@@ -278,11 +350,30 @@ int hm_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const f
         HM_GEMM_LAUNCH(1, 1, 64, 1);
     else if (small_cfg == 2)
         HM_GEMM_LAUNCH(1, 1, 64, 2);
+    else if (small_cfg == 3)
+        HM_GEMM_LAUNCH(2, 1, 64, 1);
+    else if (small_cfg == 4)
+        HM_GEMM_LAUNCH(1, 2, 64, 1);
     else
         HM_GEMM_LAUNCH(1, 1, 128, 2);
 #undef HM_GEMM_LAUNCH
     HM_CHECK_LAUNCH("hm_gemm_f32");
     return HM_OK;
+}
+
+extern "C" {
+
+int hm_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const float *A, int64_t lda,
+                const float *B, int64_t ldb, const float *bias, float *C, int64_t ldc, int accumulate,
+                void *stream) {
+    return gemm_impl(transA, transB, M, N, K, A, lda, B, ldb, bias, C, ldc, accumulate, nullptr, stream);
+}
+
+int hm_gemm_f32_ep(int transA, int transB, int64_t M, int64_t N, int64_t K, const float *A, int64_t lda,
+                   const float *B, int64_t ldb, const float *bias, float *C, int64_t ldc,
+                   const hm_gemm_epilogue *ep, void *stream) {
+    HM_CHECK_ARG(ep != nullptr, "hm_gemm_f32_ep: epilogue is NULL");
+    return gemm_impl(transA, transB, M, N, K, A, lda, B, ldb, bias, C, ldc, 0, ep, stream);
 }
 
 }  // extern "C"

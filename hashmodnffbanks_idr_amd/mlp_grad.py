@@ -23,7 +23,7 @@ import math
 import torch
 
 from . import ops
-from .ops import _softplus_call, colsum, gemm
+from .ops import EPI_ADJOINT, EPI_S1MUL, EPI_SOFTPLUS, _softplus_call, colsum, gemm, gemm_ep
 
 _SQRT2 = math.sqrt(2.0)
 
@@ -38,11 +38,12 @@ class _SdfMlp(torch.autograd.Function):
         h = e
         for l in range(L):
             a = torch.cat([h, e], 1) / _SQRT2 if l == skip_layer else h
-            z = gemm(a, Ws[l], bs[l], False, True)
+            if l < L - 1:    # z_l and h_{l+1} = softplus(z_l) from one kernel
+                z, h = gemm_ep(a, Ws[l], bs[l], False, True, EPI_SOFTPLUS, beta_sp, thr_sp)
+            else:
+                z = gemm(a, Ws[l], bs[l], False, True)
             a_list.append(a)
             z_list.append(z)
-            if l < L - 1:
-                h = _softplus_call(0, z, None, None, beta_sp, thr_sp)[0]
         zL = z_list[-1]
         s = zL[:, 0]
         rho = (1.0 / beta_rho) * (0.5 + 0.5 * s.sign() * torch.expm1(-s.abs() / beta_rho))
@@ -51,25 +52,30 @@ class _SdfMlp(torch.autograd.Function):
         c = (1.0 - sdf * sdf) / denom
         out = torch.cat([sdf.unsqueeze(-1), zL[:, 1:]], -1)
 
-        # reverse sweep for g_e = d sdf / d e
+        # reverse sweep for g_e = d sdf / d e: v_l = u_l W_l (scaled at the skip), u_{l-1} = v_l[:, :dh] * s1(z_{l-1})
+        # - the product with s1 is the epilogue of the GEMM that makes v_l
         v_list = [None] * L
         v = c.unsqueeze(-1) * Ws[L - 1][0:1, :]          # u_{L-1} is c on column 0 only: rank-1, no GEMM
+        v_list[L - 1] = v
         ge_skip = None
-        for l in range(L - 1, -1, -1):
-            if l < L - 1:
-                v = gemm(u, Ws[l], None, False, False)    # v_l = u_l W_l
+        u = _softplus_call(1, z_list[L - 2], v, None, beta_sp, thr_sp)[0] if L > 1 else None
+        for l in range(L - 2, -1, -1):
+            scale = 1.0 / _SQRT2 if l == skip_layer else 1.0
+            if l > 0:
+                dh = z_list[l - 1].shape[1]
+                v, u = gemm_ep(u, Ws[l], None, False, False, EPI_S1MUL, beta_sp, thr_sp, scale=scale,
+                               z=z_list[l - 1], nz=dh)
+            else:
+                v = gemm(u, Ws[l], None, False, False)
+                dh = v.shape[1]
             if l == skip_layer:
-                v = v / _SQRT2
-                dh = v.shape[1] - E
                 ge_skip = v[:, dh:]
                 v = v[:, :dh]
             v_list[l] = v
-            if l > 0:
-                u = _softplus_call(1, z_list[l - 1], v.contiguous(), None, beta_sp, thr_sp)[0]   # u_{l-1} = v_l * s1
         g_e = v_list[0] if ge_skip is None else v_list[0] + ge_skip
 
         ctx.meta = (L, skip_layer, beta_sp, thr_sp, E)
-        ctx.save_for_backward(e, sdf, c, denom, *Ws, *a_list, *z_list, *[t.contiguous() for t in v_list])
+        ctx.save_for_backward(e, sdf, c, denom, *Ws, *a_list, *z_list, *v_list)
         return out, g_e
 
     @staticmethod
@@ -95,13 +101,12 @@ class _SdfMlp(torch.autograd.Function):
             for l in range(L):
                 vb = torch.cat([vb_h, d_ge], 1) / _SQRT2 if l == skip_layer else vb_h
                 if l < L - 1:
-                    ub = gemm(vb, Ws[l], None, False, True)      # u-bar_l = v-bar_l W_l^T
-                    # u_l = v_{l+1}[:, :dh] * s1_l  (recomputed; one fused pass)
-                    vh_next = v_list[l + 1]
-                    u = _softplus_call(1, z_list[l], vh_next, None, beta_sp, thr_sp)[0]
+                    # u-bar_l = v-bar_l W_l^T and, on its accumulators, the adjoint of u_l = v_{l+1}[:, :dh] * s1(z_l):
+                    #   v-bar_{l+1} = u-bar * s1,  extra z-bar_l = u-bar * v_{l+1} * s2,  u_l itself (for W-bar_l)
+                    vb_h, zx[l], u = gemm_ep(vb, Ws[l], None, False, True, EPI_ADJOINT, beta_sp, thr_sp,
+                                             z=z_list[l], g=v_list[l + 1], want_out3=bool(need_w[l]))
                     if need_w[l]:
                         dW[l] = gemm(u, vb, None, True, False)   # W-bar_l = u_l^T v-bar_l
-                    vb_h, zx[l] = _softplus_call(2, z_list[l], vh_next, ub, beta_sp, thr_sp)
                 else:
                     w0 = Ws[l][0]                                # last layer: u = c * onehot(0)
                     cb = vb @ w0                                 # c-bar = u-bar[:, 0]
@@ -122,17 +127,17 @@ class _SdfMlp(torch.autograd.Function):
                     gemm(zb, a_list[l], None, True, False, out=dW[l], accumulate=True)
             if ctx.needs_input_grad[5 + L + l]:
                 db[l] = colsum(zb)
-            ab = gemm(zb, Ws[l], None, False, False)             # a-bar_l = z-bar_l W_l
-            if l == skip_layer:
-                ab = ab / _SQRT2
-                dh = ab.shape[1] - E
-                de = ab[:, dh:] if de is None else de + ab[:, dh:]
-                ab = ab[:, :dh]
             if l > 0:
-                zb = _softplus_call(1, z_list[l - 1], ab.contiguous(), None, beta_sp, thr_sp)[0]
-                if zx[l - 1] is not None:
-                    zb = zb + zx[l - 1]
+                # a-bar_l = z-bar_l W_l; z-bar_{l-1} = a-bar_l[:, :dh] * s1(z_{l-1}) (+ the adjoint sweep's share)
+                dh = z_list[l - 1].shape[1]
+                is_skip = l == skip_layer
+                ab, zb = gemm_ep(zb, Ws[l], None, False, False, EPI_S1MUL, beta_sp, thr_sp,
+                                 scale=1.0 / _SQRT2 if is_skip else 1.0, z=z_list[l - 1], g=zx[l - 1], nz=dh,
+                                 want_c=is_skip)
+                if is_skip:
+                    de = ab[:, dh:] if de is None else de + ab[:, dh:]
             else:
+                ab = gemm(zb, Ws[l], None, False, False)
                 de = ab if de is None else de + ab
         d_e = de if ctx.needs_input_grad[0] else None
         return (d_e, None, None, None, None, *dW, *db)

@@ -148,7 +148,7 @@ class ImplicitNetwork(nn.Module):
         b = self.dencity_net.beta
         key = (b.data_ptr(), b._version)
         if getattr(self, "_beta_cache", (None, None))[0] != key:
-            self._beta_cache = (key, float(self.dencity_net.get_beta()))
+            self._beta_cache = (key, float(self.dencity_net.get_beta().detach()))
         return self._beta_cache[1]
 
     def _fused(self, x, sdf_only):

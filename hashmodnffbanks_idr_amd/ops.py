@@ -189,6 +189,64 @@ def gemm(a, b, bias=None, trans_a=False, trans_b=False, out=None, accumulate=Fal
     return out
 
 
+EPI_SOFTPLUS, EPI_S1MUL, EPI_ADJOINT = 1, 2, 3
+
+
+def _rowmajor(t):
+    return t if t.stride(-1) == 1 else t.contiguous()
+
+
+def gemm_ep(a, b, bias, trans_a, trans_b, mode, beta, thr, scale=1.0, z=None, g=None, nz=None, want_c=True,
+            want_out3=False):
+    """GEMM with a fused Softplus epilogue (hm_gemm_f32_ep; include/hashmod.h).  v = (op(a) @ op(b) + bias) * scale.
+      EPI_SOFTPLUS -> (v, softplus(v))
+      EPI_S1MUL    -> (v or None, v[:, :nz] * s1(z) (+ g))
+      EPI_ADJOINT  -> (v * s1(z), v * g * s2(z), g * s1(z) or None)
+    Row-major 2-D operands with arbitrary row strides (views of wider tensors are fine); no autograd."""
+    require_gpu(a, b, bias, z, g)
+    a, b = _rowmajor(a), _rowmajor(b)
+    M, K = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
+    Kb, N = (b.shape[1], b.shape[0]) if trans_b else (b.shape[0], b.shape[1])
+    if K != Kb:
+        raise ValueError(f"hashmod gemm: inner dimensions differ ({K} vs {Kb})")
+    dev = a.device
+    new = lambda cols: torch.empty((M, cols), dtype=torch.float32, device=dev)  # noqa: E731
+    ep = _lib.GemmEpilogue()
+    ep.mode, ep.scale, ep.beta, ep.threshold = mode, float(scale), float(beta), float(thr)
+    c = new(N) if (want_c or mode == EPI_SOFTPLUS) else None
+    outs = ()
+    if mode == EPI_SOFTPLUS:
+        o1 = new(N)
+        outs = (c, o1)
+    else:
+        z = _rowmajor(z)
+        g = _rowmajor(g) if g is not None else None
+        ncol = (z.shape[1] if nz is None else nz) if mode == EPI_S1MUL else N
+        if z.shape[0] != M or z.shape[1] < ncol or (g is not None and (g.shape[0] != M or g.shape[1] < ncol)):
+            raise ValueError("hashmod gemm_ep: epilogue operand shape")
+        ep.nz = ncol
+        ep.z, ep.ldz = z.data_ptr(), z.stride(0)
+        if g is not None:
+            ep.g, ep.ldg = g.data_ptr(), g.stride(0)
+        o1 = new(ncol)
+        if mode == EPI_S1MUL:
+            outs = (c, o1)
+        else:
+            o2 = new(N)
+            o3 = new(N) if want_out3 else None
+            ep.out2, ep.ld2 = o2.data_ptr(), o2.stride(0)
+            if o3 is not None:
+                ep.out3, ep.ld3 = o3.data_ptr(), o3.stride(0)
+            outs = (o1, o2, o3)
+    ep.out1, ep.ld1 = o1.data_ptr(), o1.stride(0)
+    if bias is not None:
+        bias = bias.contiguous()
+    check(lib().hm_gemm_f32_ep(int(trans_a), int(trans_b), M, N, K, dptr(a), max(a.stride(0), 1), dptr(b),
+                               max(b.stride(0), 1), dptr(bias), dptr(c), c.stride(0) if c is not None else N,
+                               C.byref(ep), stream_ptr(a)))
+    return outs
+
+
 class _MatMul(torch.autograd.Function):
     """C = op(A) @ op(B) + bias.  backward is expressed with the same op, so autograd can
     differentiate it again (ImplicitNetwork.gradient uses create_graph=True)."""

@@ -194,6 +194,29 @@ HM_API int hm_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, 
                        const float *B, int64_t ldb, const float *bias, float *C, int64_t ldc, int accumulate,
                        void *stream);
 
+/* GEMM with a fused elementwise epilogue on v = (acc + bias) * scale - the Softplus passes that follow (forward)
+ * or consume (backward / double backward) every nn.Linear of the SDF MLP, done on the accumulator registers
+ * instead of as separate passes over [points, 512] tensors.  s1 / s2 = first / second derivative of
+ * nn.Softplus(beta, threshold) at z.  C may be NULL (raw product not stored).  No split-K, no accumulate.
+ *   HM_EPI_NONE      C = v
+ *   HM_EPI_SOFTPLUS  C = v;  out1 = softplus(v)                                   (forward: z and h in one pass)
+ *   HM_EPI_S1MUL     C = v;  out1[:, :nz] = v[:, :nz] * s1(z) (+ g)               (gradient sweeps: u = v * s1(z))
+ *   HM_EPI_ADJOINT   out1 = v * s1(z);  out2 = v * g * s2(z);  out3 = g * s1(z)    (adjoint of u = g * s1(z); out3 optional) */
+enum { HM_EPI_NONE = 0, HM_EPI_SOFTPLUS = 1, HM_EPI_S1MUL = 2, HM_EPI_ADJOINT = 3 };
+typedef struct hm_gemm_epilogue {
+    int32_t mode;
+    int32_t nz;               /* S1MUL: columns [0, nz) get the s1 product (z has nz columns)          */
+    float scale, beta, threshold;
+    const float *z;  int64_t ldz;
+    const float *g;  int64_t ldg;  /* ADJOINT: second factor;  S1MUL: optional addend (may be NULL)    */
+    float *out1;     int64_t ld1;
+    float *out2;     int64_t ld2;
+    float *out3;     int64_t ld3;
+} hm_gemm_epilogue;
+HM_API int hm_gemm_f32_ep(int transA, int transB, int64_t M, int64_t N, int64_t K, const float *A, int64_t lda,
+                          const float *B, int64_t ldb, const float *bias, float *C, int64_t ldc,
+                          const hm_gemm_epilogue *ep, void *stream);
+
 /* ---- fused activation passes of the grad-enabled MLP path ------------------------------------
  * nn.Softplus(beta, threshold) (implicit_differentiable_renderer.py:84) over n contiguous floats:
  *   order 0: out0 = softplus(z)

@@ -1,0 +1,61 @@
+"""hm_gemm_f32_ep: GEMM with the fused Softplus epilogues of the SDF MLP's gradient sweeps, against the same
+arithmetic composed from torch ops in float64 (model/implicit_differentiable_renderer.py:84,102,116-128)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BETA, THR = 100.0, 20.0
+
+
+def _s1s2(z):
+    bz = z * BETA
+    e = torch.exp(torch.clamp(bz, max=80.0))
+    s1 = torch.where(bz > THR, torch.ones_like(z), e / (e + 1))
+    s2 = torch.where(bz > THR, torch.zeros_like(z), BETA * e / (e + 1) ** 2)
+    return s1, s2
+
+
+def _close(got, ref, what):
+    # fp32 accumulation error scales with the magnitude of the products (s2 reaches beta/4 = 25)
+    atol = max(2e-5, 2e-6 * float(ref.abs().max()))
+    np.testing.assert_allclose(got.double().cpu().numpy(), ref.cpu().numpy(), rtol=2e-5, atol=atol, err_msg=what)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 445, 67), (2100, 512, 512), (64, 257, 512), (1, 5, 3)])
+def test_gemm_epilogues(M, N, K):
+    from hashmodnffbanks_idr_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    a = (torch.randn(M, K, generator=g) * 0.3).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.2).cuda()          # nn.Linear weight [out, in]
+    bias = (torch.randn(N, generator=g) * 0.1).cuda()
+    wide = (torch.randn(M, N + 9, generator=g) * 0.05).cuda()   # z / g are column views of wider tensors
+    z, gg = wide[:, 3:3 + N], (torch.randn(M, N + 4, generator=g)).cuda()[:, 4:]
+    a64, w64, b64, z64, g64 = a.double(), w.double(), bias.double(), z.double(), gg.double()
+    v64 = a64 @ w64.t() + b64
+
+    c, h = ops.gemm_ep(a, w, bias, False, True, ops.EPI_SOFTPLUS, BETA, THR)
+    _close(c, v64, "softplus: raw")
+    _close(h, torch.nn.functional.softplus(v64, beta=BETA, threshold=THR), "softplus: activation")
+
+    s1, s2 = _s1s2(z64)
+    sc = 0.7071067811865476
+    nz = max(1, N - 7)
+    c, o = ops.gemm_ep(a, w, None, False, True, ops.EPI_S1MUL, BETA, THR, scale=sc, z=z, g=gg, nz=nz)
+    raw = (a64 @ w64.t()) * sc
+    _close(c, raw, "s1mul: raw")
+    assert o.shape == (M, nz)
+    _close(o, raw[:, :nz] * s1[:, :nz] + g64[:, :nz], "s1mul: product + addend")
+    c, o = ops.gemm_ep(a, w, None, False, True, ops.EPI_S1MUL, BETA, THR, z=z, want_c=False)
+    assert c is None
+    _close(o, (a64 @ w64.t()) * s1, "s1mul: no raw, no addend")
+
+    o1, o2, o3 = ops.gemm_ep(a, w, None, False, True, ops.EPI_ADJOINT, BETA, THR, z=z, g=gg, want_out3=True)
+    ub = a64 @ w64.t()
+    _close(o1, ub * s1, "adjoint: out1")
+    _close(o2, ub * g64 * s2, "adjoint: out2")
+    _close(o3, g64 * s1, "adjoint: out3")
+    # NN form (dY * W) as the backward sweeps use it
+    wt = w.t().contiguous()                                     # [K, N]
+    c, o = ops.gemm_ep(a, wt, None, False, False, ops.EPI_S1MUL, BETA, THR, z=z)
+    _close(o, (a64 @ wt.double()) * s1, "s1mul NN")
