@@ -13,7 +13,53 @@ from torch import nn
 from torch.nn import functional as F
 
 
+class _IdrLossHip(torch.autograd.Function):
+    """terms = [loss, rgb_loss, eikonal_loss, mask_loss] from one HIP launch (csrc/hm_loss.hip) that also leaves
+    d loss / d (rgb_values, sdf_output, grad_theta); only terms[0] carries gradient."""
+
+    @staticmethod
+    def forward(ctx, rgb, sdf, grad_theta, rgb_gt, hit, inside, w_eik, w_mask, alpha):
+        from .. import _lib
+        rgb, sdf_c, rgb_gt = rgb.contiguous(), sdf.reshape(-1).contiguous(), rgb_gt.reshape(-1, 3).contiguous()
+        n = rgb.shape[0]
+        m = 0 if grad_theta is None else grad_theta.shape[0]
+        gt_c = grad_theta.contiguous() if m else None
+        hit8, in8 = hit.reshape(-1).contiguous().view(torch.uint8), inside.reshape(-1).contiguous().view(torch.uint8)
+        terms = torch.empty(4, dtype=torch.float32, device=rgb.device)
+        d_rgb, d_sdf = torch.empty_like(rgb), torch.empty_like(sdf_c)
+        d_grad = torch.empty_like(gt_c) if m else None
+        _lib.check(_lib.lib().hm_idr_loss(_lib.dptr(rgb), _lib.dptr(rgb_gt), _lib.dptr(sdf_c), _lib.dptr(hit8),
+                                          _lib.dptr(in8), n, _lib.dptr(gt_c), m, float(w_eik), float(w_mask),
+                                          float(alpha), _lib.dptr(terms), _lib.dptr(d_rgb), _lib.dptr(d_sdf),
+                                          _lib.dptr(d_grad), _lib.stream_ptr(rgb)))
+        ctx.save_for_backward(d_rgb, d_sdf, d_grad)
+        ctx.sdf_shape = sdf.shape
+        return terms
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_terms):
+        d_rgb, d_sdf, d_grad = ctx.saved_tensors
+        g = d_terms[0]
+        return (d_rgb * g, (d_sdf * g).reshape(ctx.sdf_shape), d_grad * g if d_grad is not None else None,
+                None, None, None, None, None, None)
+
+
 def idr_loss_terms(model_outputs, rgb_gt, eikonal_weight, mask_weight, alpha):
+    if model_outputs['rgb_values'].is_cuda:
+        gt = model_outputs['grad_theta']
+        terms = _IdrLossHip.apply(model_outputs['rgb_values'], model_outputs['sdf_output'],
+                                  gt if (gt is not None and gt.shape[0] > 0) else None, rgb_gt,
+                                  model_outputs['network_object_mask'], model_outputs['object_mask'],
+                                  eikonal_weight, mask_weight, alpha)
+        det = terms.detach()
+        return {'loss': terms[0], 'rgb_loss': det[1], 'eikonal_loss': det[2], 'mask_loss': det[3]}
+    return idr_loss_terms_torch(model_outputs, rgb_gt, eikonal_weight, mask_weight, alpha)
+
+
+def idr_loss_terms_torch(model_outputs, rgb_gt, eikonal_weight, mask_weight, alpha):
+    """The same terms composed from torch ops (host-side tensors: the oracle / CPU baseline leg; also the
+    checker of the HIP kernel in tests)."""
     hit = model_outputs['network_object_mask']
     inside = model_outputs['object_mask']
     n_rays = float(inside.shape[0])

@@ -230,6 +230,14 @@ HM_API int hm_softplus(int order, const float *z, const float *gy, const float *
 /* out[n] = sum over rows of x[M,N] (row stride ld) - the bias gradient of an nn.Linear.          */
 HM_API int hm_colsum(const float *x, int64_t M, int64_t N, int64_t ld, float *out, void *stream);
 
+/* ---- IDRLoss: value and gradients in one launch (code/model/loss.py:4-70) --------------------------
+ * terms[4] = {loss, rgb_loss, eikonal_loss, mask_loss};  d_rgb[n,3], d_sdf[n], d_grad[m,3] = d loss / d input.
+ * rgb, rgb_gt [n,3]; sdf [n]; hit (network_object_mask), inside (object_mask) [n] as bytes; grad_theta [m,3].  */
+HM_API int hm_idr_loss(const float *rgb, const float *rgb_gt, const float *sdf, const uint8_t *hit,
+                       const uint8_t *inside, int64_t n_rays, const float *grad_theta, int64_t n_grad,
+                       float eikonal_weight, float mask_weight, float alpha, float *terms, float *d_rgb, float *d_sdf,
+                       float *d_grad, void *stream);
+
 /* ---- optimizer tail of the training iteration ---------------------------------------------------
  * torch.nn.utils.clip_grad_norm_(parameters, max_norm) followed by torch.optim.Adam.step()
  * (training/idr_train.py:128,306-309; amsgrad / weight decay off as in the reference) over all tensors in
