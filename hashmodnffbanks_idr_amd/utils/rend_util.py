@@ -1,9 +1,68 @@
-"""Camera / ray geometry helpers on the hot path (reference: code/utils/rend_util.py:48-162).
-Image IO helpers of the reference (imageio / skimage / cv2) are out of scope.  All results are
-elementwise fp32 torch expressions evaluated on the inputs' device (the reference hard-codes
-``.cuda()``)."""
+"""Camera / ray geometry helpers on the hot path (reference: code/utils/rend_util.py:48-162) and the data
+front-end helpers next to it (rend_util.py:8-46: image / mask loading, projection-matrix decomposition) written
+against Pillow / numpy / scipy, which this image has, instead of imageio / skimage / cv2, which it has not.
+All ray-side results are elementwise fp32 torch expressions evaluated on the inputs' device (the reference
+hard-codes ``.cuda()``)."""
+import numpy as np
 import torch
 from torch.nn import functional as F
+
+
+def load_rgb(path):
+    """image file -> float32 [3, H, W] in [-1, 1] (rend_util.py:8-16: img_as_float32, then *2-1, CHW)."""
+    from PIL import Image
+    img = np.asarray(Image.open(path).convert("RGB"), dtype=np.float32) / 255.0
+    img = (img - 0.5) * 2.0
+    return img.transpose(2, 0, 1)
+
+
+def load_mask(path):
+    """mask file -> bool [H, W]: grey level > 127.5 (rend_util.py:18-23; imageio's mode='F' is Pillow's 'F')."""
+    from PIL import Image
+    alpha = np.asarray(Image.open(path).convert("F"), dtype=np.float32)
+    return alpha > 127.5
+
+
+def decompose_projection(P):
+    """P [3,4] = K [R | -R C]  ->  K (upper triangular, positive diagonal), R (rotation), C (camera centre).
+    The RQ factorisation cv2.decomposeProjectionMatrix performs (rend_util.py:33), via scipy.linalg.rq with the
+    signs fixed so that diag(K) > 0.  (cv2 is not available in this image, so this function is pinned by
+    construct-and-recover tests rather than by cv2 outputs: parity with cv2 itself is unpinned.)"""
+    from scipy.linalg import rq
+    P = np.asarray(P, dtype=np.float64)
+    M = P[:, :3]
+    K, R = rq(M)
+    D = np.diag(np.where(np.diag(K) < 0, -1.0, 1.0))
+    K, R = K @ D, D @ R
+    C = -np.linalg.solve(M, P[:, 3])
+    return K, R, C
+
+
+def load_K_Rt_from_P(filename, P=None):
+    """(intrinsics [4,4], pose [4,4] camera-to-world) from a 3x4 projection matrix or a text file holding one
+    (rend_util.py:25-46): intrinsics = K / K[2,2] in the upper-left 3x3, pose = [R^T | C]."""
+    if P is None:
+        lines = open(filename).read().splitlines()
+        if len(lines) == 4:
+            lines = lines[1:]
+        lines = [[x[0], x[1], x[2], x[3]] for x in (x.split(" ") for x in lines)]
+        P = np.asarray(lines).astype(np.float32).squeeze()
+    K, R, C = decompose_projection(P)
+    K = K / K[2, 2]
+    intrinsics = np.eye(4)
+    intrinsics[:3, :3] = K
+    pose = np.eye(4, dtype=np.float32)
+    pose[:3, :3] = R.transpose()
+    pose[:3, 3] = C
+    return intrinsics, pose
+
+
+def rot_to_quat(R):
+    """rotation matrices [B,3,3] -> quaternions (w, x, y, z) [B,4] (rend_util.py:121-139; w = sqrt(1+trace)/2)."""
+    w = torch.sqrt(1.0 + R[:, 0, 0] + R[:, 1, 1] + R[:, 2, 2]) / 2
+    d = 4 * w
+    return torch.stack([w, (R[:, 2, 1] - R[:, 1, 2]) / d, (R[:, 0, 2] - R[:, 2, 0]) / d,
+                        (R[:, 1, 0] - R[:, 0, 1]) / d], dim=1)
 
 
 def quat_to_rot(q):

@@ -56,3 +56,127 @@ def test_pack_layer_layout():
     padded[:45, 64:83] = W[:, 64:]
     for (u, g, l, s) in [(0, 0, 0, 0), (1, 10, 63, 3), (0, 8, 33, 2), (1, 3, 12, 1), (1, 7, 44, 0)]:
         assert flat[((u * n_oct + g) * 64 + l) * 4 + s] == padded[32 * u + (l & 31), 8 * g + 4 * (l >> 5) + s]
+
+
+def test_grid_uniform_layout():
+    """utils/plots.get_grid_uniform: meshgrid('xy') ordering of the reference (plots.py:227-238)."""
+    from hashmodnffbanks_idr_amd.utils import plots
+    g = plots.get_grid_uniform(5)
+    pts = g["grid_points"].numpy()
+    lin = np.linspace(-1.0, 1.0, 5).astype(np.float32)
+    assert pts.shape == (125, 3)
+    # index = iy*25 + ix*5 + iz  (numpy meshgrid default indexing='xy')
+    for iy, ix, iz in [(0, 0, 0), (1, 2, 3), (4, 0, 2), (3, 4, 4)]:
+        np.testing.assert_array_equal(pts[iy * 25 + ix * 5 + iz], [lin[ix], lin[iy], lin[iz]])
+    vol = plots.sdf_volume(lambda p: p[:, 0] + 10 * p[:, 1] + 100 * p[:, 2], g)
+    # volume[ix, iy, iz] = f(x_ix, y_iy, z_iz)
+    np.testing.assert_allclose(vol["volume"][2, 1, 3], lin[2] + 10 * lin[1] + 100 * lin[3], rtol=1e-6)
+    assert vol["has_surface"] and abs(vol["spacing"][0] - 0.5) < 1e-12
+    pc = torch.rand(100, 3) * torch.tensor([1.0, 2.0, 3.0])
+    gg = plots.get_grid(pc, 8)
+    assert gg["shortest_axis_index"] == 0 and gg["xyz"][0].shape[0] == 8
+
+
+def test_checkpoint_wire_format(tmp_path):
+    """training/checkpoints: the reference runner's directory layout and payload keys (idr_train.py:181-216),
+    state_dict keys as the reference names them, round trip into a fresh model / optimizer / scheduler."""
+    import os
+    from hashmodnffbanks_idr_amd.model.implicit_differentiable_renderer import IDRNetwork
+    from hashmodnffbanks_idr_amd.training import checkpoints as ck
+    torch.manual_seed(3)
+    model = IDRNetwork(idr_conf("tiny"))
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, [1000, 1500], gamma=0.5)
+    for p in model.parameters():
+        p.grad = torch.full_like(p, 1e-3)
+    opt.step(); sched.step()
+    ck.save_checkpoints(str(tmp_path), 7, model, opt, sched)
+    for sub in ("ModelParameters", "OptimizerParameters", "SchedulerParameters"):
+        assert sorted(os.listdir(tmp_path / sub)) == ["7.pth", "latest.pth"]
+    payload = torch.load(tmp_path / "ModelParameters" / "7.pth", weights_only=True)
+    assert set(payload) == {"epoch", "model_state_dict"} and payload["epoch"] == 7
+    keys = set(payload["model_state_dict"])
+    assert "implicit_network.embed_model.embedder_obj.levels.0.embedding.weight" in keys
+    assert "implicit_network.embed_model.embedder_obj.freq_encoding.B" in keys
+    assert {"implicit_network.lin0.weight_g", "implicit_network.lin0.weight_v", "implicit_network.lin0.bias",
+            "implicit_network.dencity_net.beta", "rendering_network.lin0.weight_g"} <= keys
+    torch.manual_seed(4)
+    model2 = IDRNetwork(idr_conf("tiny"))
+    opt2 = torch.optim.Adam(model2.parameters(), lr=1e-4)
+    sched2 = torch.optim.lr_scheduler.MultiStepLR(opt2, [1000, 1500], gamma=0.5)
+    assert ck.load_checkpoints(str(tmp_path), model2, opt2, sched2, checkpoint=7) == 7
+    for (k, a), (_, b) in zip(model.state_dict().items(), model2.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert sched2.last_epoch == sched.last_epoch
+    s1, s2 = opt.state_dict()["state"], opt2.state_dict()["state"]
+    assert all(torch.equal(s1[i]["exp_avg"], s2[i]["exp_avg"]) for i in s1)
+
+
+def _rand_rotation(rng):
+    q, r = np.linalg.qr(rng.standard_normal((3, 3)))
+    q = q @ np.diag(np.sign(np.diag(r)))
+    if np.linalg.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    return q
+
+
+def test_projection_decomposition_round_trip():
+    """load_K_Rt_from_P (reference rend_util.py:25-46, there via cv2.decomposeProjectionMatrix): construct
+    P = s K [R | -R C] and recover intrinsics (K / K[2,2]) and pose [R^T | C]; also the quaternion round trip."""
+    from hashmodnffbanks_idr_amd.utils import rend_util
+    rng = np.random.default_rng(0)
+    for trial in range(20):
+        K = np.array([[800 + 50 * rng.random(), 0.3 * rng.standard_normal(), 300 + 40 * rng.random()],
+                      [0, 790 + 50 * rng.random(), 250 + 30 * rng.random()], [0, 0, 1.0]])
+        R, C = _rand_rotation(rng), rng.standard_normal(3) * 2
+        P = (0.5 + rng.random()) * K @ np.concatenate([R, (-R @ C)[:, None]], 1)
+        intr, pose = rend_util.load_K_Rt_from_P(None, P.astype(np.float32))
+        np.testing.assert_allclose(intr[:3, :3], K, rtol=2e-4, atol=2e-3)
+        np.testing.assert_allclose(pose[:3, :3], R.T, atol=2e-5)
+        np.testing.assert_allclose(pose[:3, 3], C, rtol=2e-4, atol=2e-4)
+        assert pose.dtype == np.float32 and intr.shape == (4, 4) and intr[3, 3] == 1
+    Rb = torch.from_numpy(np.stack([_rand_rotation(rng) for _ in range(8)])).float()
+    q = rend_util.rot_to_quat(Rb)
+    ok = (1.0 + Rb[:, 0, 0] + Rb[:, 1, 1] + Rb[:, 2, 2]) > 0.1      # the formula divides by w
+    np.testing.assert_allclose(rend_util.quat_to_rot(q)[ok].numpy(), Rb[ok].numpy(), atol=1e-5)
+
+
+def test_scene_dataset(tmp_path):
+    """datasets/scene_dataset.SceneDataset on a synthetic two-image scan in the DTU layout (scene_dataset.py:8-117)."""
+    from PIL import Image
+    from hashmodnffbanks_idr_amd.datasets.scene_dataset import SceneDataset
+    H, W = 6, 8
+    scan = tmp_path / "DTU" / "scan65"
+    (scan / "image").mkdir(parents=True)
+    (scan / "mask").mkdir()
+    rng = np.random.default_rng(1)
+    cams, imgs, masks = {}, [], []
+    for i in range(2):
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        msk = (rng.random((H, W)) > 0.5).astype(np.uint8) * 255
+        Image.fromarray(img).save(scan / "image" / f"{i:06d}.png")
+        Image.fromarray(np.stack([msk] * 3, -1)).save(scan / "mask" / f"{i:03d}.png")
+        imgs.append(img); masks.append(msk > 127)
+        K = np.array([[50.0, 0, 4], [0, 50, 3], [0, 0, 1]])
+        R, C = _rand_rotation(rng), rng.standard_normal(3)
+        wm = np.eye(4); wm[:3] = K @ np.concatenate([R, (-R @ C)[:, None]], 1)
+        sm = np.diag([2.0, 2.0, 2.0, 1.0]); sm[:3, 3] = [0.1, -0.2, 0.3]
+        cams[f"world_mat_{i}"], cams[f"scale_mat_{i}"] = wm, sm
+    np.savez(scan / "cameras.npz", **cams)
+    ds = SceneDataset(False, "DTU", [H, W], scan_id=65, root=str(tmp_path))
+    assert len(ds) == 2 and ds.total_pixels == H * W
+    idx, sample, gt = ds[1]
+    assert sample["uv"].shape == (H * W, 2) and sample["intrinsics"].shape == (4, 4) and sample["pose"].shape == (4, 4)
+    np.testing.assert_array_equal(sample["uv"][W + 2].numpy(), [2.0, 1.0])      # pixel (row 1, col 2) -> (x=2, y=1)
+    np.testing.assert_allclose(gt["rgb"].numpy(), imgs[1].reshape(-1, 3) / 255.0 * 2 - 1, atol=1e-6)
+    np.testing.assert_array_equal(sample["object_mask"].numpy(), masks[1].reshape(-1))
+    ds.change_sampling_idx(10)
+    _, s2, g2 = ds[0]
+    assert s2["uv"].shape == (10, 2) and g2["rgb"].shape == (10, 3) and s2["object_mask"].shape == (10,)
+    batch = ds.collate_fn([ds[0], ds[1]])
+    assert batch[0].tolist() == [0, 1] and batch[1]["uv"].shape == (2, 10, 2) and batch[2]["rgb"].shape == (2, 10, 3)
+    # the pose is the camera centre / rotation of P = world_mat @ scale_mat (scaled world)
+    P = (cams["world_mat_0"] @ cams["scale_mat_0"])[:3]
+    centre = -np.linalg.solve(P[:, :3], P[:, 3])
+    np.testing.assert_allclose(ds.pose_all[0][:3, 3].numpy(), centre, rtol=1e-4, atol=1e-4)
+    assert ds.get_gt_pose().shape == (2, 4, 4) and ds.get_scale_mat().shape == (4, 4)

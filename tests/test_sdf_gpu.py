@@ -252,3 +252,18 @@ def test_fused_mlp_grad_node_matches_generic_autograd(golden, tag, cfg):
     assert p1.keys() == p2.keys()
     for n in p1:
         close(p1[n], p2[n], n)
+
+
+def test_sdf_volume_matches_chunked_forward(golden):
+    """utils/plots.sdf_volume (mesh-extraction caller of the fused kernel, reference plots.py:110-128) against
+    the reference's own procedure: 10 000-point chunks of the layer-by-layer forward."""
+    from hashmodnffbanks_idr_amd.utils import plots
+    g = golden("sdf_full")
+    net = _net(g, "C1")
+    grid = plots.get_grid_uniform(33, "cuda")
+    vol = plots.sdf_volume(net.sdf, grid)
+    # grad mode on: ImplicitNetwork.forward takes the layer-by-layer (GEMM) route
+    z = torch.cat([net(p)[:, 0].detach() for p in torch.split(grid["grid_points"], 10000, dim=0)]).cpu().numpy()
+    ref = z.reshape(33, 33, 33).transpose([1, 0, 2])
+    _close(vol["volume"], ref, what="sdf volume")
+    assert vol["volume"].shape == (33, 33, 33)
