@@ -217,9 +217,33 @@ def cpu_baseline(model, n_rays=256, reps=2):
     for _ in range(reps):
         one()
     dt = (time.perf_counter() - t0) / reps
+    # the reference runner pins torch to ONE thread (training/idr_train.py:21): time that configuration too, on a
+    # smaller sample (SURVEY.md 8d asks for both)
+    n1 = 32
+    inp, gt = synthetic_batch(1234, n1, "cpu")
+    torch.set_num_threads(1)
+    try:
+        one()
+        t0 = time.perf_counter()
+        one()
+        dt1 = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(cores)
+    cpu_model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                cpu_model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {"value": round(n_rays / dt, 2), "unit": "rays/s", "cores": cores, "kind": "port",
             "sample": f"{n_rays} of {RAYS_PER_GPU} rays, {reps} fwd+loss+bwd steps of oracle/torch_ref.py (torch-CPU, "
-                      f"{cores} threads), {dt:.2f} s/step"}
+                      f"{cores} threads), {dt:.2f} s/step",
+            "cpu_model": cpu_model,
+            "single_thread": {"value": round(n1 / dt1, 2), "unit": "rays/s", "cores": 1,
+                              "sample": f"{n1} rays, 1 step, torch.set_num_threads(1) as the reference runner does, "
+                                        f"{dt1:.2f} s/step"}}
 
 
 def main():

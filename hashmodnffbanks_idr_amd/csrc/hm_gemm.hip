@@ -298,10 +298,10 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K, co
     // tile choice: big tiles only when they still fill the chip
     const int64_t t128 = ((M + 127) / 128) * ((N + 127) / 128);
     static const int small_cfg = [] { const char *e = getenv("HM_GEMM_CFG"); return e ? atoi(e) : 0; }();
-    const bool big = t128 >= 256 || small_cfg == 5;
-    // experiment configs (HM_GEMM_CFG): 3 = 128x64 tile, 4 = 64x128 tile (BK 64, 4 waves)
-    const int64_t bm = big ? 128 : (small_cfg == 3 ? 128 : 64), bn = big ? 128 : (small_cfg == 4 ? 128 : 64);
-    const int64_t kBK = big ? 32 : (small_cfg >= 1 && small_cfg <= 4 ? 64 : 128);
+    const bool big = t128 >= 256;
+    // (128x64 / 64x128 tiles and a forced 128x128 tile were measured too: 30-45 % slower on M = 1750...4822)
+    const int64_t bm = big ? 128 : 64, bn = big ? 128 : 64;
+    const int64_t kBK = big ? 32 : (small_cfg == 1 || small_cfg == 2 ? 64 : 128);
     const int64_t tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
     int64_t split = 1;
     if (tiles < 256 && K >= 256 && g.ep.mode == HM_EPI_NONE) {   // (a nonlinear epilogue needs the full sum)
@@ -350,10 +350,6 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K, co
         HM_GEMM_LAUNCH(1, 1, 64, 1);
     else if (small_cfg == 2)
         HM_GEMM_LAUNCH(1, 1, 64, 2);
-    else if (small_cfg == 3)
-        HM_GEMM_LAUNCH(2, 1, 64, 1);
-    else if (small_cfg == 4)
-        HM_GEMM_LAUNCH(1, 2, 64, 1);
     else
         HM_GEMM_LAUNCH(1, 1, 128, 2);
 #undef HM_GEMM_LAUNCH
