@@ -526,7 +526,9 @@ constexpr int kPts8 = 8;
 constexpr int kRing8 = 5;    // weight ring depth of the 8-point body (k-blocks)
 constexpr int kGroupFloats8 = kPts8 * 4;
 
-template <int FRAC>
+// PTS = 8: two point groups per tile; PTS = 4: one (<= 1024 live points: the second group's MFMAs are skipped,
+// the LDS image keeps its 8-point stride)
+template <int FRAC, int PTS>
 __device__ __forceinline__ void sdf_m8_body(const HmLevels &lv, const SdfNet &net, const float *__restrict__ x,
                                             int64_t n, const float *__restrict__ table,
                                             const float *__restrict__ Bf, float *__restrict__ out,
@@ -544,11 +546,12 @@ __device__ __forceinline__ void sdf_m8_body(const HmLevels &lv, const SdfNet &ne
     const int jj = (lane & 15) >> 2; // feature quad within the 16-feature tile
     const int p4 = lane & 3;         // point within a group of four
     const int L = lv.L, F = lv.F, E = lv.E;
-    const int64_t n_tiles = (n + kPts8 - 1) / kPts8;
+    constexpr bool TWO = PTS == 8;
+    const int64_t n_tiles = (n + PTS - 1) / PTS;
 
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int64_t base = tile * kPts8;
-        const int cnt = (int)min((int64_t)kPts8, n - base);
+        const int64_t base = tile * PTS;
+        const int cnt = (int)min((int64_t)PTS, n - base);
         __syncthreads();
         if (tid < kPts8 * 3) SX[tid] = (tid < cnt * 3) ? x[base * 3 + tid] : 0.0f;
         __syncthreads();
@@ -679,18 +682,18 @@ __device__ __forceinline__ void sdf_m8_body(const HmLevels &lv, const SdfNet &ne
                         const float *src = (t < nb0) ? src0 + (4 * t + q) * kGroupFloats8
                                                      : src1 + (4 * (t - nb0) + q) * kGroupFloats8;
                         const float4 b0 = *reinterpret_cast<const float4 *>(src + p4 * 4);
-                        const float4 b1 = *reinterpret_cast<const float4 *>(src + (p4 + 4) * 4);
+                        const float4 b1 = TWO ? *reinterpret_cast<const float4 *>(src + (p4 + 4) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                         for (int a = 0; a < 4; ++a) {
                             const float4 av = ring[u][a];
                             acc0[a] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.x, b0.x, acc0[a], 0, 0, 0);
-                            acc1[a] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.x, b1.x, acc1[a], 0, 0, 0);
+                            if (TWO) acc1[a] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.x, b1.x, acc1[a], 0, 0, 0);
                             acc0[a] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.y, b0.y, acc0[a], 0, 0, 0);
-                            acc1[a] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.y, b1.y, acc1[a], 0, 0, 0);
+                            if (TWO) acc1[a] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.y, b1.y, acc1[a], 0, 0, 0);
                             acc0[a] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.z, b0.z, acc0[a], 0, 0, 0);
-                            acc1[a] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.z, b1.z, acc1[a], 0, 0, 0);
+                            if (TWO) acc1[a] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.z, b1.z, acc1[a], 0, 0, 0);
                             acc0[a] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.w, b0.w, acc0[a], 0, 0, 0);
-                            acc1[a] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.w, b1.w, acc1[a], 0, 0, 0);
+                            if (TWO) acc1[a] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.w, b1.w, acc1[a], 0, 0, 0);
                         }
                     }
                 }
@@ -714,7 +717,7 @@ __device__ __forceinline__ void sdf_m8_body(const HmLevels &lv, const SdfNet &ne
                         const float keep0 = hi2 ? acc0[a + 2][r] : acc0[a][r], send0 = hi2 ? acc0[a][r] : acc0[a + 2][r];
                         const float keep1 = hi2 ? acc1[a + 2][r] : acc1[a][r], send1 = hi2 ? acc1[a][r] : acc1[a + 2][r];
                         k0[a][r] = keep0 + __shfl_xor(send0, 32);
-                        k1[a][r] = keep1 + __shfl_xor(send1, 32);
+                        k1[a][r] = TWO ? keep1 + __shfl_xor(send1, 32) : 0.0f;
                     }
                 }
 #pragma unroll
@@ -722,7 +725,7 @@ __device__ __forceinline__ void sdf_m8_body(const HmLevels &lv, const SdfNet &ne
                     const float keep0 = hi1 ? k0[1][r] : k0[0][r], send0 = hi1 ? k0[0][r] : k0[1][r];
                     const float keep1 = hi1 ? k1[1][r] : k1[0][r], send1 = hi1 ? k1[0][r] : k1[1][r];
                     r0[r] = keep0 + __shfl_xor(send0, 16);
-                    r1[r] = keep1 + __shfl_xor(send1, 16);
+                    r1[r] = TWO ? keep1 + __shfl_xor(send1, 16) : 0.0f;
                 }
             }
             __syncthreads();
@@ -741,7 +744,7 @@ __device__ __forceinline__ void sdf_m8_body(const HmLevels &lv, const SdfNet &ne
                 }
                 float *dst = X + (f >> 2) * kGroupFloats8;
                 *reinterpret_cast<float4 *>(dst + p4 * 4) = make_float4(v[0], v[1], v[2], v[3]);
-                *reinterpret_cast<float4 *>(dst + (p4 + 4) * 4) = make_float4(v[4], v[5], v[6], v[7]);
+                if (TWO) *reinterpret_cast<float4 *>(dst + (p4 + 4) * 4) = make_float4(v[4], v[5], v[6], v[7]);
             }
             if (li == 0) {
                 for (int i = tid; i < emb_groups16 * kGroupFloats8; i += kThreadsSdf) EMB[i] = __fdiv_rn(EMB[i], sqrt2);
@@ -770,12 +773,15 @@ __global__ __launch_bounds__(kThreadsSdf, 1) void sdf_fwd_small_kernel(HmLevels 
                                                                         const float *__restrict__ Bf,
                                                                         float *__restrict__ out, int64_t out_stride,
                                                                         int out_cols, const int32_t *__restrict__ n_dev,
-                                                                        int64_t run_min, int64_t run_max, int64_t m8_max) {
+                                                                        int64_t run_min, int64_t run_max, int64_t m8_max,
+                                                                        int64_t m4_max) {
     extern __shared__ __align__(16) float lds[];
     if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));
     if (n < run_min || n > run_max) return;
-    if (n <= m8_max)
-        sdf_m8_body<FRAC>(lv, net, x, n, table, Bf, out, out_stride, out_cols, lds);
+    if (n <= m4_max)
+        sdf_m8_body<FRAC, 4>(lv, net, x, n, table, Bf, out, out_stride, out_cols, lds);
+    else if (n <= m8_max)
+        sdf_m8_body<FRAC, 8>(lv, net, x, n, table, Bf, out, out_stride, out_cols, lds);
     else
         sdf_m16_body<FRAC>(lv, net, x, n, table, Bf, out, out_stride, out_cols, lds);
 }
@@ -793,8 +799,8 @@ int hm_sdf_fwd(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *x,
     HM_CHECK_ARG(n >= 0, "hm_sdf_fwd: n < 0");
     HM_CHECK_ARG(frac_mode == HM_FRAC_REFERENCE || frac_mode == HM_FRAC_TRILINEAR, "hm_sdf_fwd: bad frac_mode");
     HM_CHECK_ARG(mlp->n_layers >= 1 && mlp->n_layers <= HM_MAX_LAYERS, "hm_sdf_fwd: n_layers out of range");
-    HM_CHECK_ARG(tile_points == 0 || tile_points == 8 || tile_points == 16 || tile_points == 64,
-                 "hm_sdf_fwd: tile_points must be 0, 8, 16 or 64");
+    HM_CHECK_ARG(tile_points == 0 || tile_points == 4 || tile_points == 8 || tile_points == 16 || tile_points == 64,
+                 "hm_sdf_fwd: tile_points must be 0, 4, 8, 16 or 64");
     const HmLevels &lv = desc->lv;
     SdfNet net;
     net.n_layers = mlp->n_layers;
@@ -835,8 +841,8 @@ int hm_sdf_fwd(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *x,
     const hm_mlp_layer &last = mlp->layer[mlp->n_layers - 1];
     HM_CHECK_ARG(out_cols == 1 || out_cols == last.out_dim, "hm_sdf_fwd: out_cols must be 1 or the last layer's out_dim");
     HM_CHECK_ARG(out_stride >= out_cols, "hm_sdf_fwd: out_stride < out_cols");
-    HM_CHECK_ARG((tile_points != 16 && tile_points != 8) || have16,
-                 "hm_sdf_fwd: tile_points 8 / 16 need w_packed_m16 in every layer");
+    HM_CHECK_ARG((tile_points != 16 && tile_points != 8 && tile_points != 4) || have16,
+                 "hm_sdf_fwd: tile_points 4 / 8 / 16 need w_packed_m16 in every layer");
     if (n == 0) return HM_OK;
     HM_CHECK_ARG(x && table && B_fourier && out, "hm_sdf_fwd: NULL pointer");
     // small batches: 16-point tiles spread the call over the whole chip (see sdf_fwd_m16_kernel).
@@ -847,14 +853,16 @@ int hm_sdf_fwd(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *x,
     bool run16 = false, run64 = false;
     int64_t lo16 = 0, hi16 = kBig, lo64 = 0, hi64 = kBig;
     // 8-point tiles below kTiny live points (one tile per CU), 16-point tiles up to kSmall, 64 above
-    constexpr int64_t kTiny = 2048;
-    int64_t m8_max = 0;
+    // (4-point tiles below kMini: same weight stream, a quarter of the 16-point tile's matrix work)
+    constexpr int64_t kTiny = 2048, kMini = 1024;
+    int64_t m8_max = 0, m4_max = 0;
     if (tile_points == 8) { run16 = true; m8_max = kBig; }
+    else if (tile_points == 4) { run16 = true; m8_max = kBig; m4_max = kBig; }
     else if (tile_points == 16) run16 = true;
     else if (tile_points == 64 || !have16) run64 = true;
-    else if (!n_dev) { run16 = n <= kSmall; run64 = !run16; m8_max = kTiny; }
-    else if (n <= kSmall) { run16 = true; m8_max = kTiny; }
-    else { run16 = run64 = true; hi16 = kSmall; lo64 = kSmall + 1; m8_max = kTiny; }
+    else if (!n_dev) { run16 = n <= kSmall; run64 = !run16; m8_max = kTiny; m4_max = kMini; }
+    else if (n <= kSmall) { run16 = true; m8_max = kTiny; m4_max = kMini; }
+    else { run16 = run64 = true; hi16 = kSmall; lo64 = kSmall + 1; m8_max = kTiny; m4_max = kMini; }
     static thread_local bool attr_done = false;
     if (!attr_done) {  // opt in to >64 KB dynamic LDS once (not a stream operation)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sdf_fwd_kernel<HM_FRAC_REFERENCE>),
@@ -875,16 +883,20 @@ int hm_sdf_fwd(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *x,
             const int64_t n8 = nmax < m8_max ? nmax : m8_max;
             tiles = max(tiles, (n8 + kPts8 - 1) / kPts8);
         }
+        if (m4_max > 0) {
+            const int64_t n4 = nmax < m4_max ? nmax : m4_max;
+            tiles = max(tiles, (n4 + 3) / 4);
+        }
         const int64_t cap = max_workgroups > 0 ? max_workgroups : 256;  // one resident workgroup per CU
         const int64_t grid = tiles < cap ? tiles : cap;
         if (frac_mode == HM_FRAC_REFERENCE)
             hipLaunchKernelGGL(sdf_fwd_small_kernel<HM_FRAC_REFERENCE>, dim3((unsigned)grid), dim3(kThreadsSdf), lds,
                                as_stream(stream), lv, net, x, n, table, B_fourier, out, out_stride, out_cols, n_dev,
-                               lo16, hi16, m8_max);
+                               lo16, hi16, m8_max, m4_max);
         else
             hipLaunchKernelGGL(sdf_fwd_small_kernel<HM_FRAC_TRILINEAR>, dim3((unsigned)grid), dim3(kThreadsSdf), lds,
                                as_stream(stream), lv, net, x, n, table, B_fourier, out, out_stride, out_cols, n_dev,
-                               lo16, hi16, m8_max);
+                               lo16, hi16, m8_max, m4_max);
     }
     if (run64) {
         const size_t lds = sizeof(float) * ((size_t)(net.x_groups + net.emb_groups) * kGroupFloats + kPts * 4 +

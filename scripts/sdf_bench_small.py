@@ -6,7 +6,7 @@ import torch, bench
 from hashmodnffbanks_idr_amd.model.implicit_differentiable_renderer import IDRNetwork
 torch.manual_seed(0)
 net = IDRNetwork(bench.idr_conf("C2")).cuda().implicit_network
-for n, tile in ((16, 8), (480, 8), (2048, 8), (16, 16), (2048, 16), (4096, 16)):
+for n, tile in ((16, 4), (480, 4), (1024, 4), (480, 8), (1024, 8), (2048, 8), (2048, 16), (4096, 16)):
     net.sdf_tile_points = tile
     x = torch.rand(n, 3, device="cuda") * 2 - 1
     for _ in range(3):

@@ -22,7 +22,7 @@ def _close(a, b, rtol=1e-5, atol=2e-6, what=""):
     np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, err_msg=what)
 
 
-@pytest.mark.parametrize("tile", [8, 16, 64])
+@pytest.mark.parametrize("tile", [4, 8, 16, 64])
 @pytest.mark.parametrize("tag,cfg", CASES)
 def test_fused_forward_golden(golden, tag, cfg, tile):
     g = golden(f"sdf_{tag}")
@@ -36,7 +36,7 @@ def test_fused_forward_golden(golden, tag, cfg, tile):
     _close(sdf.cpu().numpy(), g["out"][:, 0], what="fused sdf-only output")
 
 
-@pytest.mark.parametrize("tile", [0, 8, 16, 64])
+@pytest.mark.parametrize("tile", [0, 4, 8, 16, 64])
 @pytest.mark.parametrize("n", [1, 15, 17, 63, 64, 65, 1000, 64 * 300 + 5])
 def test_fused_forward_vs_oracle_ragged(golden, n, tile):
     g = golden("sdf_full")
@@ -163,7 +163,7 @@ def test_fused_device_side_count():
     emb = net.embed_model.embedder_obj
     x = torch.from_numpy(P.make_points(2, 500)).cuda()
     full = net.sdf(x)
-    for tile in (8, 16, 64):
+    for tile in (4, 8, 16, 64):
         n_dev = torch.tensor([137], dtype=torch.int32, device="cuda")
         pk = net.packed_weights()
         res = ops.sdf_fwd(emb.desc, pk, x, emb.table.detach(), emb.freq_encoding.B, 0, sdf_only=True,
