@@ -547,6 +547,7 @@ __device__ __forceinline__ void sdf_m8_body(const HmLevels &lv, const SdfNet &ne
     const int p4 = lane & 3;         // point within a group of four
     const int L = lv.L, F = lv.F, E = lv.E;
     constexpr bool TWO = PTS == 8;
+    constexpr int RD8 = kRing8;   // (one block deeper for the 4-point variant measured the same: 94 vs 93 us)
     const int64_t n_tiles = (n + PTS - 1) / PTS;
 
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -599,7 +600,7 @@ __device__ __forceinline__ void sdf_m8_body(const HmLevels &lv, const SdfNet &ne
         }
         __syncthreads();
 
-        float4 ring[kRing8][4];
+        float4 ring[RD8][4];
         bool ring_ready = false;
         auto prefetch8 = [&](int l) {
             const hm_mlp_layer &Lp = net.layer[l];
@@ -609,7 +610,7 @@ __device__ __forceinline__ void sdf_m8_body(const HmLevels &lv, const SdfNet &ne
             const size_t ts = (size_t)nbp * 64;
             const size_t p1 = (1 < ntp ? 1 : 0) * ts, p2 = (2 < ntp ? 2 : 0) * ts, p3 = (3 < ntp ? 3 : 0) * ts;
 #pragma unroll
-            for (int st = 0; st < kRing8 - 1; ++st) {
+            for (int st = 0; st < RD8 - 1; ++st) {
                 const size_t off = (size_t)min(st, nbp - 1) * 64;
                 ring[st][0] = Ap[off]; ring[st][1] = Ap[p1 + off]; ring[st][2] = Ap[p2 + off]; ring[st][3] = Ap[p3 + off];
             }
@@ -667,17 +668,17 @@ __device__ __forceinline__ void sdf_m8_body(const HmLevels &lv, const SdfNet &ne
                 const float *src1 = (Ly.seg_src[1] == 0) ? X : EMB;
                 if (!ring_ready) prefetch8(li);
                 ring_ready = false;
-                for (int tt = 0; tt < nb; tt += kRing8) {
+                for (int tt = 0; tt < nb; tt += RD8) {
 #pragma unroll
-                    for (int u = 0; u < kRing8; ++u) {
+                    for (int u = 0; u < RD8; ++u) {
                         const int t = tt + u;
                         if (t >= nb) break;
                         {
-                            const size_t off = (size_t)min(t + kRing8 - 1, nb - 1) * 64;
-                            ring[(u + kRing8 - 1) % kRing8][0] = A[off];
-                            ring[(u + kRing8 - 1) % kRing8][1] = A[o1 + off];
-                            ring[(u + kRing8 - 1) % kRing8][2] = A[o2 + off];
-                            ring[(u + kRing8 - 1) % kRing8][3] = A[o3 + off];
+                            const size_t off = (size_t)min(t + RD8 - 1, nb - 1) * 64;
+                            ring[(u + RD8 - 1) % RD8][0] = A[off];
+                            ring[(u + RD8 - 1) % RD8][1] = A[o1 + off];
+                            ring[(u + RD8 - 1) % RD8][2] = A[o2 + off];
+                            ring[(u + RD8 - 1) % RD8][3] = A[o3 + off];
                         }
                         const float *src = (t < nb0) ? src0 + (4 * t + q) * kGroupFloats8
                                                      : src1 + (4 * (t - nb0) + q) * kGroupFloats8;
