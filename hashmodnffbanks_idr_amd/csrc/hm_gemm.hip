@@ -103,15 +103,17 @@ __device__ __forceinline__ void store_tile(float *__restrict__ S, bool kcontig, 
 // EP: compiled with the fused epilogues (kept out of the plain instantiation: its extra registers would drop the
 // 64x64 configuration from two resident workgroups per CU to one).  The 8-wave configuration is held to 128 VGPRs
 // (4 waves per SIMD = two workgroups per CU).
-template <int TM, int TN, int BK, int KS, bool VA, bool VB, bool EP>
-__global__ __launch_bounds__(256 * KS, (KS == 2 ? 4 : 1)) void gemm_f32_kernel(GemmArgs g) {
-    constexpr int BM = 64 * TM, BN = 64 * TN, NT = 256 * KS;
-    __shared__ __align__(16) float As[BK * BM];
-    __shared__ __align__(16) float Bs[BK * BN];
+// WM: wave rows of the tile (2 -> 64*TM rows; 1 -> 32*TM rows for row counts that would leave the 64-row grid
+// with fewer than two workgroups per CU); the wave columns are always 2.
+template <int TM, int TN, int BK, int KS, bool VA, bool VB, bool EP, int WM = 2>
+__global__ __launch_bounds__(128 * WM * KS, (WM * KS == 4 ? 4 : 1)) void gemm_f32_kernel(GemmArgs g) {
+    constexpr int BM = 32 * WM * TM, BN = 64 * TN, NT = 128 * WM * KS, WG = 2 * WM;  // WG = waves per k part
+    __shared__ __align__(16) float smem[BK * (BM + BN)];
+    float *As = smem, *Bs = smem + BK * BM;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
-    const int kpart = wave >> 2;
-    const int wm = (wave >> 1) & 1, wn = wave & 1;
+    const int kpart = wave / WG, wsub = wave % WG;
+    const int wm = wsub >> 1, wn = wsub & 1;
     const int j = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int kbeg = blockIdx.z * g.k_chunk;
@@ -167,17 +169,18 @@ __global__ __launch_bounds__(256 * KS, (KS == 2 ? 4 : 1)) void gemm_f32_kernel(G
         // sum the wave groups' partial tiles through LDS (the staging buffers are free now)
         static_assert(KS == 1 || (TM == 1 && TN == 1), "intra-workgroup K split is built for the 64x64 tile");
         __syncthreads();
-        float *red = As;  // (KS-1) * 4 waves * 16 regs * 64 lanes floats  <= BK*BM
+        float *red = smem;  // (KS-1) * WG waves * 16 regs * 64 lanes floats
+        static_assert((KS - 1) * WG * 16 * 64 <= BK * (BM + BN), "K-split reduction does not fit the staging buffers");
         if (kpart > 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) red[(((kpart - 1) * 4 + (wave & 3)) * 16 + r) * 64 + lane] = acc[0][0][r];
+            for (int r = 0; r < 16; ++r) red[(((kpart - 1) * WG + wsub) * 16 + r) * 64 + lane] = acc[0][0][r];
         }
         __syncthreads();
         if (kpart > 0) return;
 #pragma unroll
         for (int p = 0; p < KS - 1; ++p)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[0][0][r] += red[((p * 4 + (wave & 3)) * 16 + r) * 64 + lane];
+            for (int r = 0; r < 16; ++r) acc[0][0][r] += red[((p * WG + wsub) * 16 + r) * 64 + lane];
     }
 
     // epilogue: lane holds column n, registers hold rows (r&3) + 8(r>>2) + 4h
@@ -300,7 +303,13 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K, co
     static const int small_cfg = [] { const char *e = getenv("HM_GEMM_CFG"); return e ? atoi(e) : 0; }();
     const bool big = t128 >= 256;
     // (128x64 / 64x128 tiles and a forced 128x128 tile were measured too: 30-45 % slower on M = 1750...4822)
-    const int64_t bm = big ? 128 : 64, bn = big ? 128 : 64;
+    // 32-row tiles (HM_GEMM_HALF=1) for row counts whose 64-row grid gives a CU fewer than two workgroups
+    // (M = 2048...3072, N = 512).  Measured: the training step is 2 % SLOWER with them (10.50 vs 10.28 ms) -
+    // twice the B-panel traffic outweighs the extra overlap - so they stay off.
+    const int64_t t64 = ((M + 63) / 64) * ((N + 63) / 64);
+    static const int half_cfg = [] { const char *e = getenv("HM_GEMM_HALF"); return e ? atoi(e) : 0; }();
+    const bool half_rows = !big && small_cfg == 0 && half_cfg != 0 && t64 >= 128 && t64 < 512 && M >= 256;
+    const int64_t bm = big ? 128 : (half_rows ? 32 : 64), bn = big ? 128 : 64;
     const int64_t kBK = big ? 32 : (small_cfg == 1 || small_cfg == 2 ? 64 : 128);
     const int64_t tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
     int64_t split = 1;
@@ -323,35 +332,37 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K, co
     }
     dim3 grid((unsigned)((M + bm - 1) / bm), (unsigned)((N + bn - 1) / bn), (unsigned)split);
     HM_CHECK_ARG(grid.y <= 65535u && grid.z <= 65535u, "hm_gemm_f32: N or split too large for one launch");
-#define HM_GEMM_LAUNCH(TM_, TN_, BK_, KS_)                                                                      \
+#define HM_GEMM_LAUNCH(TM_, TN_, BK_, KS_, WM_)                                                                     \
     do {                                                                                                        \
         if (g.ep.mode != HM_EPI_NONE) {                                                                         \
             if (g.vecA && g.vecB)                                                                               \
-                hipLaunchKernelGGL((gemm_f32_kernel<TM_, TN_, BK_, KS_, true, true, true>), grid, dim3(256 * KS_), 0, st, g); \
+                hipLaunchKernelGGL((gemm_f32_kernel<TM_, TN_, BK_, KS_, true, true, true, WM_>), grid, dim3(128 * WM_ * KS_), 0, st, g); \
             else if (g.vecA)                                                                                    \
-                hipLaunchKernelGGL((gemm_f32_kernel<TM_, TN_, BK_, KS_, true, false, true>), grid, dim3(256 * KS_), 0, st, g); \
+                hipLaunchKernelGGL((gemm_f32_kernel<TM_, TN_, BK_, KS_, true, false, true, WM_>), grid, dim3(128 * WM_ * KS_), 0, st, g); \
             else if (g.vecB)                                                                                    \
-                hipLaunchKernelGGL((gemm_f32_kernel<TM_, TN_, BK_, KS_, false, true, true>), grid, dim3(256 * KS_), 0, st, g); \
+                hipLaunchKernelGGL((gemm_f32_kernel<TM_, TN_, BK_, KS_, false, true, true, WM_>), grid, dim3(128 * WM_ * KS_), 0, st, g); \
             else                                                                                                \
-                hipLaunchKernelGGL((gemm_f32_kernel<TM_, TN_, BK_, KS_, false, false, true>), grid, dim3(256 * KS_), 0, st, g); \
+                hipLaunchKernelGGL((gemm_f32_kernel<TM_, TN_, BK_, KS_, false, false, true, WM_>), grid, dim3(128 * WM_ * KS_), 0, st, g); \
         } else if (g.vecA && g.vecB)                                                                            \
-            hipLaunchKernelGGL((gemm_f32_kernel<TM_, TN_, BK_, KS_, true, true, false>), grid, dim3(256 * KS_), 0, st, g); \
+            hipLaunchKernelGGL((gemm_f32_kernel<TM_, TN_, BK_, KS_, true, true, false, WM_>), grid, dim3(128 * WM_ * KS_), 0, st, g); \
         else if (g.vecA)                                                                                        \
-            hipLaunchKernelGGL((gemm_f32_kernel<TM_, TN_, BK_, KS_, true, false, false>), grid, dim3(256 * KS_), 0, st, g); \
+            hipLaunchKernelGGL((gemm_f32_kernel<TM_, TN_, BK_, KS_, true, false, false, WM_>), grid, dim3(128 * WM_ * KS_), 0, st, g); \
         else if (g.vecB)                                                                                        \
-            hipLaunchKernelGGL((gemm_f32_kernel<TM_, TN_, BK_, KS_, false, true, false>), grid, dim3(256 * KS_), 0, st, g); \
+            hipLaunchKernelGGL((gemm_f32_kernel<TM_, TN_, BK_, KS_, false, true, false, WM_>), grid, dim3(128 * WM_ * KS_), 0, st, g); \
         else                                                                                                    \
-            hipLaunchKernelGGL((gemm_f32_kernel<TM_, TN_, BK_, KS_, false, false, false>), grid, dim3(256 * KS_), 0, st, g); \
+            hipLaunchKernelGGL((gemm_f32_kernel<TM_, TN_, BK_, KS_, false, false, false, WM_>), grid, dim3(128 * WM_ * KS_), 0, st, g); \
     } while (0)
     hipStream_t st = as_stream(stream);
     if (big)
-        HM_GEMM_LAUNCH(2, 2, 32, 1);
+        HM_GEMM_LAUNCH(2, 2, 32, 1, 2);
     else if (small_cfg == 1)
-        HM_GEMM_LAUNCH(1, 1, 64, 1);
+        HM_GEMM_LAUNCH(1, 1, 64, 1, 2);
     else if (small_cfg == 2)
-        HM_GEMM_LAUNCH(1, 1, 64, 2);
+        HM_GEMM_LAUNCH(1, 1, 64, 2, 2);
+    else if (half_rows)
+        HM_GEMM_LAUNCH(1, 1, 128, 4, 1);
     else
-        HM_GEMM_LAUNCH(1, 1, 128, 2);
+        HM_GEMM_LAUNCH(1, 1, 128, 2, 2);
 #undef HM_GEMM_LAUNCH
     HM_CHECK_LAUNCH("hm_gemm_f32");
     return HM_OK;
