@@ -77,3 +77,52 @@ def test_graphed_step_matches_eager_static_step():
         assert abs(x - y) <= 2e-3 * abs(y) + 1e-6, (la, lb)
     for n in pa:
         assert (pa[n] - pb[n]).abs().max().item() <= 5e-4, n
+
+
+def test_graph_contains_no_memset_or_memcpy_nodes_of_ours(tmp_path):
+    """Regression guard for the round-1 replay fault: hipMemsetAsync / hipMemcpyAsync calls recorded into the
+    captured iteration (tracer cursor array, column-sum outputs, tracer statistics) lost their order under
+    back-to-back replays.  The library's own fills / copies are kernels now: the captured forward+backward graph
+    must hold no MEMSET node at all (torch's zero_/zeros are fill kernels) and stay a pure chain."""
+    import os
+    import re
+    from hashmodnffbanks_idr_amd.training.graph_step import GraphedTrainStep
+    from hashmodnffbanks_idr_amd.training.optim import ClipAdam
+    model, loss_fn, inp, gt = _setup()
+    os.environ["HM_GRAPH_DUMP"] = str(tmp_path)
+    try:
+        stepper = GraphedTrainStep(model, loss_fn, ClipAdam(model.parameters(), lr=1e-4), warmup=2)
+        torch.manual_seed(9)
+        for _ in range(4):
+            out, lo = stepper.step(inp, gt)
+    finally:
+        os.environ.pop("HM_GRAPH_DUMP", None)
+    assert stepper.g_fb is not None, "graph capture fell back to eager"
+    dot = open(tmp_path / "g_fb.dot").read()
+    kinds = re.findall(r'label="\{\s*\n?(\w+)\n', dot)
+    assert kinds.count("KERNEL") > 100
+    assert kinds.count("MEMSET") == 0, "a MEMSET node is back in the captured iteration"
+    edges = re.findall(r'"(graph_\d+_node_\d+)"\s*->\s*"(graph_\d+_node_\d+)"', dot)
+    assert len(edges) == len(kinds) - 1, "captured iteration is no longer a single chain"
+    opt_dot = open(tmp_path / "g_opt.dot").read()
+    assert len(re.findall(r'label="\{\s*\n?KERNEL\n', opt_dot)) <= 8      # clip + Adam: begin, norm, update (+ few)
+    assert np.isfinite(lo["loss"].item())
+
+
+def test_run_ahead_replays_with_a_device_sync_in_between():
+    """The access pattern that used to fault: replays that run ahead of the host with one device-wide
+    synchronisation somewhere in between (sync_each_step=False).  Counters and loss must stay sane."""
+    from hashmodnffbanks_idr_amd.training.graph_step import GraphedTrainStep
+    from hashmodnffbanks_idr_amd.training.optim import ClipAdam
+    model, loss_fn, inp, gt = _setup()
+    stepper = GraphedTrainStep(model, loss_fn, ClipAdam(model.parameters(), lr=1e-4), warmup=2, sync_each_step=False)
+    torch.manual_seed(9)
+    for i in range(30):
+        if i == 5:
+            torch.cuda.synchronize()
+        out, lo = stepper.step(inp, gt)
+    torch.cuda.synchronize()
+    st = model.ray_tracer.last_stats
+    assert np.isfinite(lo["loss"].item())
+    assert st["rays"] == 512 and st["unfinished"] == 0 and 0 <= st["sampler_rays"] <= 512
+    assert 512 <= st["sdf_evals"] <= 512 * 2 * 41 + 512 * 208
