@@ -212,11 +212,17 @@ def cpu_baseline(model, n_rays=256, reps=2):
         ref.zero_grad()
         lo["loss"].backward()
 
-    one()
-    t0 = time.perf_counter()
-    for _ in range(reps):
+    # thread sweep on the same sample: with ~2000 small ops per step the all-core setting is not the fastest one
+    sweep = []
+    for nt in sorted({cores, min(cores, 16)}, reverse=True):
+        torch.set_num_threads(nt)
         one()
-    dt = (time.perf_counter() - t0) / reps
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            one()
+        sweep.append((nt, (time.perf_counter() - t0) / reps))
+    torch.set_num_threads(cores)
+    best_threads, dt = min(sweep, key=lambda t: t[1])
     # the reference runner pins torch to ONE thread (training/idr_train.py:21): time that configuration too, on a
     # smaller sample (SURVEY.md 8d asks for both)
     n1 = 32
@@ -237,10 +243,11 @@ def cpu_baseline(model, n_rays=256, reps=2):
                 break
     except OSError:
         pass
-    return {"value": round(n_rays / dt, 2), "unit": "rays/s", "cores": cores, "kind": "port",
+    return {"value": round(n_rays / dt, 2), "unit": "rays/s", "cores": best_threads, "kind": "port",
             "sample": f"{n_rays} of {RAYS_PER_GPU} rays, {reps} fwd+loss+bwd steps of oracle/torch_ref.py (torch-CPU, "
-                      f"{cores} threads), {dt:.2f} s/step",
-            "cpu_model": cpu_model,
+                      f"best of the thread sweep: {best_threads} threads), {dt:.2f} s/step",
+            "threads_sweep": [{"threads": nt, "rays_per_s": round(n_rays / t, 2)} for nt, t in sweep],
+            "host_cores": cores, "cpu_model": cpu_model,
             "single_thread": {"value": round(n1 / dt1, 2), "unit": "rays/s", "cores": 1,
                               "sample": f"{n1} rays, 1 step, torch.set_num_threads(1) as the reference runner does, "
                                         f"{dt1:.2f} s/step"}}
