@@ -104,3 +104,41 @@ def test_device_tracer_equals_generic_tracer(golden, tag, mode):
 def test_device_tracer_equals_generic_tracer_2048_rays(golden):
     st = _device_vs_host("bumpy", golden, "train", n_rays=2048, seed=11)
     assert st["sdf_evals"] > 2048 * 20
+
+
+@pytest.mark.parametrize("case", ["one_ray", "all_miss_sphere", "mask_all_false", "mask_all_true", "odd_count"])
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_device_tracer_edge_cases(golden, case, mode):
+    """Degenerate batches the reference's masked code paths handle implicitly (ray_tracing.py:46-95: empty
+    selections, rays that miss the bounding sphere, no / all rays inside the object mask): device tracer ==
+    generic tracer, bit for bit."""
+    from hashmodnffbanks_idr_amd.model.ray_tracing import RayTracing
+    import params as P
+    g = golden("raytrace_bumpy")
+    net = make_implicit("C1", (512,) * 8, 256, int(g["seed"]), float(g["perturb"]), float(g["table_scale"]))
+    net.eval()
+    net.sdf_tile_points = 64
+    n = {"one_ray": 1, "odd_count": 77}.get(case, 64)
+    cam, dirs = P.make_rays(5, n)
+    om = np.random.RandomState(5).uniform(0, 1, n) < 0.6
+    if case == "all_miss_sphere":
+        dirs = -dirs                      # every ray points away from the unit sphere
+    if case == "mask_all_false":
+        om[:] = False
+    if case == "mask_all_true":
+        om[:] = True
+    outs = []
+    for dev_tracer in (True, False):
+        rt = RayTracing(1.0, 5.0e-5, 0.5, 3, 10, 100, 8).cuda()
+        rt.train(mode == "train")
+        rt.use_device_tracer = dev_tracer
+        rt.steps_override = torch.from_numpy(g["steps"])
+        with torch.no_grad():
+            outs.append(rt(sdf=net.sdf, cam_loc=torch.from_numpy(cam).cuda(), object_mask=torch.from_numpy(om).cuda(),
+                           ray_directions=torch.from_numpy(np.ascontiguousarray(dirs)).cuda()))
+    (p1, m1, d1), (p2, m2, d2) = outs
+    assert p1.shape == (n, 3) and m1.shape == (n,) and d1.shape == (n,)
+    assert torch.equal(m1, m2)
+    assert torch.equal(d1, d2) and torch.equal(p1, p2)
+    if case == "all_miss_sphere":
+        assert not bool(m1.any())
