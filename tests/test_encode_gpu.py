@@ -110,3 +110,40 @@ def test_cpu_tensor_fails_loudly():
     emb, _, _ = _embedder("tiny", 3, 0.5)
     with pytest.raises(HashmodError):
         emb(torch.zeros(4, 3))
+
+
+@pytest.mark.parametrize("cfg", ["C2", "C4"])
+def test_encode_full_size_properties(cfg):
+    """BASELINE-size launch (2^22 points, the bench's gather workload) checked through properties that do not
+    need the oracle to run 4 M points: (a) a 4096-row sample equals the oracle bit for bit (hash features),
+    (b) permuting the points permutes the rows, bit for bit, (c) the hash features are linear in the table:
+    doubling the table doubles them exactly (power of two), (d) table backward is the exact adjoint of the
+    forward: <d_out, encode(T)> = <T, encode_bwd(d_out)> for the hash columns."""
+    from hashmodnffbanks_idr_amd import ops
+    n = 1 << 22
+    emb, table, B = _embedder(cfg, 31, 0.5)
+    L, T, b, d = P.CONFIGS[cfg]
+    nf = 3 + 2 * L
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    x = (torch.rand((n, 3), generator=g) * 2 - 1).cuda()
+    tab, Bf = emb.table.detach(), emb.freq_encoding.B
+    out = ops.encode_fwd(emb.desc, x, tab, Bf, 0)
+    idx = torch.randint(0, n, (4096,), generator=g)
+    ref = O.encode_fwd(O.Grid(L, T, b, d), x[idx.cuda()].cpu().numpy(), table, B, 0)
+    got = out[idx.cuda()].cpu().numpy()
+    assert np.array_equal(got[:, nf:], ref[:, nf:])
+    np.testing.assert_allclose(got[:, :nf], ref[:, :nf], atol=1e-5, rtol=0)
+    perm = torch.randperm(n, generator=g).cuda()
+    out_p = ops.encode_fwd(emb.desc, x[perm].contiguous(), tab, Bf, 0)
+    assert torch.equal(out_p, out[perm])
+    del out_p
+    out2 = ops.encode_fwd(emb.desc, x, (tab * 2).contiguous(), Bf, 0)
+    assert torch.equal(out2[:, nf:], out[:, nf:] * 2)
+    assert torch.equal(out2[:, :nf], out[:, :nf])
+    del out2
+    m = 1 << 18                                        # adjoint identity on a 262 144-point slice (fp64 sums)
+    d_feat = torch.randn((m, L * 2), generator=g).cuda()
+    d_table = ops.encode_bwd_table(emb.desc, x[:m].contiguous(), d_feat, 0)
+    lhs = (out[:m, nf:].double() * d_feat.double()).sum().item()
+    rhs = (tab.double() * d_table.double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-6 * max(1.0, abs(lhs)), (lhs, rhs)

@@ -267,3 +267,28 @@ def test_sdf_volume_matches_chunked_forward(golden):
     ref = z.reshape(33, 33, 33).transpose([1, 0, 2])
     _close(vol["volume"], ref, what="sdf volume")
     assert vol["volume"].shape == (33, 33, 33)
+
+
+@pytest.mark.parametrize("tile", [4, 16, 64])
+def test_fused_forward_full_size_properties(golden, tile):
+    """bench-size launch (2^18 points) of the fused SDF kernel: a 512-point sample against the oracle, and
+    permutation equivariance bit for bit (a point's value may not depend on its tile neighbours or position)."""
+    g = golden("sdf_full")
+    net = _net(g, "C1")
+    net.sdf_tile_points = tile
+    n = 1 << 18 if tile != 4 else 1 << 16
+    gen = torch.Generator(device="cpu").manual_seed(99)
+    x = (torch.rand((n, 3), generator=gen) * 2.1 - 1.05).cuda()
+    with torch.no_grad():
+        s = net.sdf(x)
+        perm = torch.randperm(n, generator=gen).cuda()
+        sp = net.sdf(x[perm].contiguous())
+    assert torch.equal(sp, s[perm])
+    L, T, b, d = P.CONFIGS["C1"]
+    seed = int(g["seed"])
+    levels, B, _, _ = P.make_embedder_state(seed, "C1", float(g["table_scale"]))
+    prm = P.make_sdf_params(seed + 7, 3 + 4 * L, (512,) * 8, 257, (4,), 0.6, float(g["perturb"]), 0.1)
+    orc = O.SdfOracle(O.Grid(L, T, b, d), np.concatenate(levels, 0), B, prm)
+    idx = torch.randint(0, n, (512,), generator=gen)
+    ref = orc(x[idx.cuda()].cpu().numpy())
+    _close(s[idx.cuda()].cpu().numpy(), ref[:, 0], what="sample vs oracle")
