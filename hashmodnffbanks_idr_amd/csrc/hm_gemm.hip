@@ -97,6 +97,67 @@ __device__ __forceinline__ void store_tile(float *__restrict__ S, bool kcontig, 
     }
 }
 
+// Store one 32x32 accumulator tile: lane holds column n, registers hold rows mrow0 + (r&3) + 8(r>>2)
+// (mrow0 already includes the lane half's +4).  EP selects the fused Softplus epilogues (include/hashmod.h).
+template <bool EP>
+__device__ __forceinline__ void gemm_store_tile(const GemmArgs &g, const f32x16 &acc, int n, int mrow0, bool add_bias) {
+    const float bv = add_bias ? g.bias[n] : 0.0f;
+    const int mode = EP ? g.ep.mode : (int)HM_EPI_NONE;
+    // epilogue operands first, all 16 (+16) loads in flight together on clamped addresses: a load under
+    // a per-row guard would be waited for one at a time
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+    float zv[8], gv[8];
+    if (mode >= HM_EPI_S1MUL) {
+        const int nc = mode == HM_EPI_S1MUL ? min(n, g.ep.nz - 1) : n;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = 8 * half + q;
+            const int mc = min(mrow0 + (r & 3) + 8 * (r >> 2), g.M - 1);
+            zv[q] = g.ep.z[(int64_t)mc * g.ep.ldz + nc];
+        }
+        if (g.ep.g) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r = 8 * half + q;
+                const int mc = min(mrow0 + (r & 3) + 8 * (r >> 2), g.M - 1);
+                gv[q] = g.ep.g[(int64_t)mc * g.ep.ldg + nc];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) gv[q] = 0.0f;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int r = 8 * half + q;
+        const int m = mrow0 + (r & 3) + 8 * (r >> 2);
+        if (m >= g.M) continue;
+        float v = acc[r] + bv;
+        if (mode != HM_EPI_NONE) v *= g.ep.scale;
+        if (g.C) {
+            float *dst = g.C + (int64_t)m * g.ldc + n;
+            if (g.atomic)
+                atomicAdd(dst, v);
+            else
+                *dst = v;
+        }
+        if (mode == HM_EPI_SOFTPLUS) {
+            g.ep.out1[(int64_t)m * g.ep.ld1 + n] = hm_softplus_fwd(v, g.ep.beta, g.ep.threshold);
+        } else if (mode == HM_EPI_S1MUL) {
+            if (n < g.ep.nz)
+                g.ep.out1[(int64_t)m * g.ep.ld1 + n] =
+                    v * hm_sp_deriv(zv[q], g.ep.beta, g.ep.threshold).s1 + gv[q];
+        } else if (mode == HM_EPI_ADJOINT) {
+            const SpDeriv d = hm_sp_deriv(zv[q], g.ep.beta, g.ep.threshold);
+            g.ep.out1[(int64_t)m * g.ep.ld1 + n] = v * d.s1;
+            g.ep.out2[(int64_t)m * g.ep.ld2 + n] = v * gv[q] * d.s2;
+            if (g.ep.out3) g.ep.out3[(int64_t)m * g.ep.ld3 + n] = gv[q] * d.s1;
+        }
+    }
+    }
+}
+
 // KS = intra-workgroup K split: 4*KS waves, wave group g multiplies octets [g*BK/8/KS, (g+1)*BK/8/KS) of every
 // stage, partial tiles are summed through LDS at the end.  Two waves per SIMD keep the matrix pipe busy
 // while the next stage's loads are in flight even when the grid has only one workgroup per CU.
@@ -191,63 +252,127 @@ __global__ __launch_bounds__(128 * WM * KS, (WM * KS == 4 ? 4 : 1)) void gemm_f3
         for (int tn = 0; tn < TN; ++tn) {
             const int n = n0 + wn * 32 * TN + tn * 32 + j;
             if (n >= g.N) continue;
-            const float bv = add_bias ? g.bias[n] : 0.0f;
-            const int mode = EP ? g.ep.mode : (int)HM_EPI_NONE;
-            const int mrow0 = m0 + wm * 32 * TM + tm * 32 + 4 * h;
-            // epilogue operands first, all 16 (+16) loads in flight together on clamped addresses: a load under
-            // a per-row guard would be waited for one at a time
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-            float zv[8], gv[8];
-            if (mode >= HM_EPI_S1MUL) {
-                const int nc = mode == HM_EPI_S1MUL ? min(n, g.ep.nz - 1) : n;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int r = 8 * half + q;
-                    const int mc = min(mrow0 + (r & 3) + 8 * (r >> 2), g.M - 1);
-                    zv[q] = g.ep.z[(int64_t)mc * g.ep.ldz + nc];
-                }
-                if (g.ep.g) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int r = 8 * half + q;
-                        const int mc = min(mrow0 + (r & 3) + 8 * (r >> 2), g.M - 1);
-                        gv[q] = g.ep.g[(int64_t)mc * g.ep.ldg + nc];
-                    }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) gv[q] = 0.0f;
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int r = 8 * half + q;
-                const int m = mrow0 + (r & 3) + 8 * (r >> 2);
-                if (m >= g.M) continue;
-                float v = acc[tm][tn][r] + bv;
-                if (mode != HM_EPI_NONE) v *= g.ep.scale;
-                if (g.C) {
-                    float *dst = g.C + (int64_t)m * g.ldc + n;
-                    if (g.atomic)
-                        atomicAdd(dst, v);
-                    else
-                        *dst = v;
-                }
-                if (mode == HM_EPI_SOFTPLUS) {
-                    g.ep.out1[(int64_t)m * g.ep.ld1 + n] = hm_softplus_fwd(v, g.ep.beta, g.ep.threshold);
-                } else if (mode == HM_EPI_S1MUL) {
-                    if (n < g.ep.nz)
-                        g.ep.out1[(int64_t)m * g.ep.ld1 + n] =
-                            v * hm_sp_deriv(zv[q], g.ep.beta, g.ep.threshold).s1 + gv[q];
-                } else if (mode == HM_EPI_ADJOINT) {
-                    const SpDeriv d = hm_sp_deriv(zv[q], g.ep.beta, g.ep.threshold);
-                    g.ep.out1[(int64_t)m * g.ep.ld1 + n] = v * d.s1;
-                    g.ep.out2[(int64_t)m * g.ep.ld2 + n] = v * gv[q] * d.s2;
-                    if (g.ep.out3) g.ep.out3[(int64_t)m * g.ep.ld3 + n] = gv[q] * d.s1;
-                }
-            }
-            }
+            gemm_store_tile<EP>(g, acc[tm][tn], n, m0 + wm * 32 * TM + tm * 32 + 4 * h, add_bias);
         }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Pipelined 64x64 tile for the training shapes (M = 2048...4096 rows, N = K = 512: 256-512 tiles, i.e. ONE or two
+// workgroups per CU, 6.8 us of matrix work each).  With so little work per tile the steady state of the software
+// pipeline has to be tight: 32-deep K stages (16 of them at K = 512), global loads issued kPipeD-1 stages ahead into
+// a register ring, two LDS buffers, and the MFMA operands of a stage held in registers (two sets) so that the LDS
+// round trip of stage s+1 - store, the ONE barrier of the stage, fragment reads - is issued in the middle of stage
+// s's MFMAs.  (A wave that has passed the barrier of stage s has read the fragments of stage s-1's buffer long
+// before, so that buffer is free to refill.)  The loop body has NO conditionals - the host launches this kernel
+// only when every tile is interior and the K range is a whole number of kPipeD-stage groups - because with the
+// generic kernel's guards in it hipcc keeps the accumulators in VGPRs across the back edge and copies all 32 of
+// them to AGPRs and back every stage.
+// AKC / BKC: operand is k-contiguous and 16-B aligned (one dwordx4 per k-group), else row-contiguous (four dwords).
+constexpr int kPipeBK = 32, kPipeD = 4;
+
+template <bool KC, int PER>
+__device__ __forceinline__ void pipe_fetch(const float *const (&p)[PER], int64_t step, int64_t ld, int sc,
+                                           float4 (&x)[PER]) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const float *q = p[i] + sc * step;
+        if (KC) {   // (component-wise: a whole-struct float4 copy into the array keeps it in scratch memory)
+            const float4 t = *reinterpret_cast<const float4 *>(q);
+            x[i] = make_float4(t.x, t.y, t.z, t.w);
+        } else {
+            x[i] = make_float4(q[0], q[ld], q[2 * ld], q[3 * ld]);
+        }
+    }
+}
+template <int OCT>
+__device__ __forceinline__ void pipe_read_ops(const float *as, const float *bs, int arow, int brow, int h,
+                                              float4 (&xa)[OCT], float4 (&xb)[OCT]) {
+#pragma unroll
+    for (int oo = 0; oo < OCT; ++oo) {
+        const int kg = 2 * oo + h;
+        xa[oo] = *reinterpret_cast<const float4 *>(as + lds_slot<64>(kg, arow));
+        xb[oo] = *reinterpret_cast<const float4 *>(bs + lds_slot<64>(kg, brow));
+    }
+}
+__device__ __forceinline__ void pipe_mfma_oct(const float4 &a, const float4 &b, f32x16 &c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, c, 0, 0, 0);
+}
+
+
+template <bool AKC, bool BKC, bool EP>
+__global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(GemmArgs g) {
+    constexpr int BM = 64, BN = 64, BK = kPipeBK, NT = 256, PER = BM * BK / 4 / NT, KG = BK / 4, OCT = BK / 8;
+    __shared__ __align__(16) float As[2][BK * BM];
+    __shared__ __align__(16) float Bs[2][BK * BN];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int j = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int kbeg = blockIdx.z * g.k_chunk;
+    const int stages = g.k_chunk / BK;   // multiple of kPipeD (host)
+
+    const float *pa[PER], *pb[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int e = tid + NT * i;
+        pa[i] = AKC ? g.A + (int64_t)(m0 + e / KG) * g.lda + kbeg + (e % KG) * 4
+                    : g.A + (int64_t)(kbeg + (e / BM) * 4) * g.lda + m0 + e % BM;
+        pb[i] = BKC ? g.B + (int64_t)(n0 + e / KG) * g.ldb + kbeg + (e % KG) * 4
+                    : g.B + (int64_t)(kbeg + (e / BN) * 4) * g.ldb + n0 + e % BN;
+    }
+    const int64_t sa = AKC ? BK : (int64_t)BK * g.lda, sb = BKC ? BK : (int64_t)BK * g.ldb;
+    const int64_t lda = g.lda, ldb = g.ldb;
+    f32x16 acc, acc2;   // even / odd k-octets: two independent MFMA chains for the one wave on each SIMD
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = acc2[r] = 0.0f;
+    // the four ring slots and the two operand sets are separate named arrays (an array indexed by (u+3)%4 inside
+    // the unrolled loop was demoted to scratch memory by hipcc)
+    static_assert(kPipeD == 4, "the stage macro below is written out for a 4-deep ring (8-deep measured no faster)");
+    float4 ra0[PER], ra1[PER], ra2[PER], ra3[PER], rb0[PER], rb1[PER], rb2[PER], rb3[PER];
+    float4 opa0[OCT], opa1[OCT], opb0[OCT], opb1[OCT];
+#define HM_PIPE_FETCH(S_, RA_, RB_)                                                                 \
+    do {                                                                                            \
+        const int sc_ = min((S_), stages - 1); /* past the end: re-read the last stage, never multiplied */ \
+        pipe_fetch<AKC, PER>(pa, sa, lda, sc_, RA_);                                                \
+        pipe_fetch<BKC, PER>(pb, sb, ldb, sc_, RB_);                                                \
+    } while (0)
+    HM_PIPE_FETCH(0, ra0, rb0);
+    HM_PIPE_FETCH(1, ra1, rb1);
+    HM_PIPE_FETCH(2, ra2, rb2);
+    store_tile<BM, BK, NT>(As[0], AKC, tid, ra0);
+    store_tile<BN, BK, NT>(Bs[0], BKC, tid, rb0);
+    __syncthreads();
+    pipe_read_ops<OCT>(As[0], Bs[0], wm * 32 + j, wn * 32 + j, h, opa0, opb0);
+// one stage: multiply from operand set C, meanwhile fetch stage s+D-1 into ring slot F and move ring slot N (stage
+// s+1) through LDS buffer NB into operand set X
+#define HM_PIPE_STAGE(S_, F_, N_, C_, X_, NB_)                                                      \
+    do {                                                                                            \
+        HM_PIPE_FETCH((S_) + kPipeD - 1, ra##F_, rb##F_);                                                    \
+        pipe_mfma_oct(opa##C_[0], opb##C_[0], acc);                                                 \
+        pipe_mfma_oct(opa##C_[1], opb##C_[1], acc2);                                                \
+        store_tile<BM, BK, NT>(As[NB_], AKC, tid, ra##N_);                                          \
+        store_tile<BN, BK, NT>(Bs[NB_], BKC, tid, rb##N_);                                          \
+        __syncthreads();                                                                            \
+        pipe_read_ops<OCT>(As[NB_], Bs[NB_], wm * 32 + j, wn * 32 + j, h, opa##X_, opb##X_);        \
+        pipe_mfma_oct(opa##C_[2], opb##C_[2], acc);                                                 \
+        pipe_mfma_oct(opa##C_[3], opb##C_[3], acc2);                                                \
+    } while (0)
+    static_assert(OCT == 4, "HM_PIPE_STAGE is written for 4 octets per stage");
+    for (int s0 = 0; s0 < stages; s0 += kPipeD) {
+        HM_PIPE_STAGE(s0 + 0, 3, 1, 0, 1, 1);
+        HM_PIPE_STAGE(s0 + 1, 0, 2, 1, 0, 0);
+        HM_PIPE_STAGE(s0 + 2, 1, 3, 0, 1, 1);
+        HM_PIPE_STAGE(s0 + 3, 2, 0, 1, 0, 0);
+    }
+#undef HM_PIPE_STAGE
+#undef HM_PIPE_FETCH
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
+    gemm_store_tile<EP>(g, acc, n0 + wn * 32 + j, m0 + wm * 32 + 4 * h, (g.bias != nullptr) && (blockIdx.z == 0));
 }
 
 // zero an M x N window of C (split-K accumulates with atomics); a plain kernel instead of
@@ -310,7 +435,12 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K, co
     static const int half_cfg = [] { const char *e = getenv("HM_GEMM_HALF"); return e ? atoi(e) : 0; }();
     const bool half_rows = !big && small_cfg == 0 && half_cfg != 0 && t64 >= 128 && t64 < 512 && M >= 256;
     const int64_t bm = big ? 128 : (half_rows ? 32 : 64), bn = big ? 128 : 64;
-    const int64_t kBK = big ? 32 : (small_cfg == 1 || small_cfg == 2 ? 64 : 128);
+    static const int pipe_cfg = [] { const char *e = getenv("HM_GEMM_PIPE"); return e ? atoi(e) : 1; }();
+    // the pipelined kernel takes only regular problems: whole 64x64 tiles, K a whole number of 128-deep groups per
+    // split, operands either k-contiguous + 16-B aligned or row-contiguous
+    const bool use_pipe = !big && small_cfg == 0 && !half_rows && pipe_cfg != 0 && M % 64 == 0 && N % 64 == 0 &&
+                          K % (kPipeBK * kPipeD) == 0 && K > 0 && (!a_kc || g.vecA) && (!b_kc || g.vecB);
+    const int64_t kBK = big ? 32 : (use_pipe ? kPipeBK * kPipeD : (small_cfg == 1 || small_cfg == 2 ? 64 : 128));
     const int64_t tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
     int64_t split = 1;
     if (tiles < 256 && K >= 256 && g.ep.mode == HM_EPI_NONE) {   // (a nonlinear epilogue needs the full sum)
@@ -324,6 +454,7 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K, co
     if (k_chunk == 0) k_chunk = kBK;
     split = K > 0 ? (K + k_chunk - 1) / k_chunk : 1;
     g.k_chunk = (int)k_chunk;
+    const bool pipe_ok = use_pipe && K % k_chunk == 0;   // (the pipelined kernel has no K-tail handling)
     g.atomic = (accumulate || split > 1) ? 1 : 0;
     if (split > 1 && !accumulate) {
         // split-K accumulates with atomics into a zeroed C
@@ -361,7 +492,20 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K, co
         HM_GEMM_LAUNCH(1, 1, 64, 2, 2);
     else if (half_rows)
         HM_GEMM_LAUNCH(1, 1, 128, 4, 1);
-    else
+    else if (pipe_ok) {
+#define HM_PIPE_LAUNCH(AKC_, BKC_)                                                                                \
+    do {                                                                                                          \
+        if (g.ep.mode != HM_EPI_NONE)                                                                             \
+            hipLaunchKernelGGL((gemm_f32_pipe_kernel<AKC_, BKC_, true>), grid, dim3(256), 0, st, g);              \
+        else                                                                                                      \
+            hipLaunchKernelGGL((gemm_f32_pipe_kernel<AKC_, BKC_, false>), grid, dim3(256), 0, st, g);             \
+    } while (0)
+        if (a_kc && b_kc) HM_PIPE_LAUNCH(true, true);
+        else if (a_kc) HM_PIPE_LAUNCH(true, false);
+        else if (b_kc) HM_PIPE_LAUNCH(false, true);
+        else HM_PIPE_LAUNCH(false, false);
+#undef HM_PIPE_LAUNCH
+    } else
         HM_GEMM_LAUNCH(1, 1, 128, 2, 2);
 #undef HM_GEMM_LAUNCH
     HM_CHECK_LAUNCH("hm_gemm_f32");
