@@ -444,7 +444,8 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K, co
     const int64_t tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
     int64_t split = 1;
     if (tiles < 256 && K >= 256 && g.ep.mode == HM_EPI_NONE) {   // (a nonlinear epilogue needs the full sum)
-        split = (512 + tiles - 1) / tiles;
+        static const int split_target = [] { const char *e = getenv("HM_GEMM_SPLIT_TARGET"); return e ? atoi(e) : 512; }();
+        split = (split_target + tiles - 1) / tiles;
         const int64_t max_split = K / 128;
         if (split > max_split) split = max_split;
         if (split < 1) split = 1;
