@@ -55,6 +55,8 @@ class GradAllReducer:
         self.params = [p for p in params if p.requires_grad]
         self.big_numel = big_numel
         self._flat = None
+        self._flat_key = None
+        self._views = None
 
     def __call__(self):
         if not dist.is_initialized() or dist.get_world_size() == 1:
@@ -74,29 +76,26 @@ class GradAllReducer:
             (big if p.numel() >= self.big_numel else small).append(p)
         works = []
         for p in big:
+            if not p.grad.is_contiguous():
+                p.grad = p.grad.contiguous()
             works.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True))
-        flat = None
         if small:
-            n = sum(p.numel() for p in small)
-            if self._flat is None or self._flat.numel() != n or self._flat.device != dev:
-                self._flat = torch.empty(n, dtype=torch.float32, device=dev)
-            flat = self._flat
-            o = 0
-            for p in small:
-                flat[o:o + p.numel()].copy_(p.grad.reshape(-1))
-                o += p.numel()
-            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
+            key = tuple((p.data_ptr(), p.numel()) for p in small)
+            if self._flat is None or self._flat_key != key or self._flat.device != dev:
+                self._flat = torch.empty(sum(p.numel() for p in small), dtype=torch.float32, device=dev)
+                self._views = [v.view_as(p) for v, p in zip(self._flat.split([p.numel() for p in small]), small)]
+                self._flat_key = key
+            grads = [p.grad for p in small]
+            torch._foreach_copy_(self._views, grads)          # one multi-tensor launch instead of one copy per tensor
+            works.append(dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, async_op=True))
         for w in works:
             w.wait()
         inv = 1.0 / world
-        for p in big:
-            p.grad.mul_(inv)
+        if big:
+            torch._foreach_mul_([p.grad for p in big], inv)
         if small:
-            flat.mul_(inv)
-            o = 0
-            for p in small:
-                p.grad.copy_(flat[o:o + p.numel()].view_as(p.grad))
-                o += p.numel()
+            self._flat.mul_(inv)
+            torch._foreach_copy_(grads, self._views)
 
 
 def train_step(model, loss_fn, optimizer, model_input, ground_truth, reducer=None, max_norm=1.0):
