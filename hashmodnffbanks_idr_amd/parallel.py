@@ -54,6 +54,7 @@ class GradAllReducer:
     def __init__(self, params, big_numel=1 << 20):
         self.params = [p for p in params if p.requires_grad]
         self.big_numel = big_numel
+        self.assume_dense = False   # set by GraphedTrainStep once the iteration is a replayed static graph
         self._flat = None
         self._flat_key = None
         self._views = None
@@ -64,9 +65,12 @@ class GradAllReducer:
         world = dist.get_world_size()
         dev = self.params[0].device
         # a parameter may have no gradient on one rank only (e.g. no surface hit in its shard): agree first
-        have = torch.tensor([0 if p.grad is None else 1 for p in self.params], device=dev, dtype=torch.int32)
-        dist.all_reduce(have, op=dist.ReduceOp.MAX)
-        have = have.tolist()
+        if self.assume_dense and all(p.grad is not None for p in self.params):
+            have = [1] * len(self.params)      # replayed static iteration: every rank has every gradient, no handshake
+        else:
+            have = torch.tensor([0 if p.grad is None else 1 for p in self.params], device=dev, dtype=torch.int32)
+            dist.all_reduce(have, op=dist.ReduceOp.MAX)
+            have = have.tolist()
         big, small = [], []
         for p, h in zip(self.params, have):
             if not h:

@@ -140,6 +140,8 @@ class GraphedTrainStep:
                 with torch.cuda.graph(g_opt, stream=self.side, capture_error_mode=mode):
                     self._update()
                 self.g_fb, self.g_opt = g_fb, g_opt
+                if self.reducer is not None and hasattr(self.reducer, "assume_dense"):
+                    self.reducer.assume_dense = True     # every replay produces every gradient on every rank
                 if dump:
                     g_fb.debug_dump(os.path.join(dump, "g_fb.dot"))
                     g_opt.debug_dump(os.path.join(dump, "g_opt.dot"))
