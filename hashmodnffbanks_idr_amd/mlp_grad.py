@@ -29,17 +29,33 @@ _SQRT2 = math.sqrt(2.0)
 
 
 class _SdfMlp(torch.autograd.Function):
+    """The weight gradient of a hidden layer l is  u_l^T v-bar_l + z-bar_l^T a_l  (adjoint of the gradient sweep +
+    backward of the forward sweep).  Both products share the point dimension, so they run as ONE GEMM over stacked
+    operands [u_l; z-bar_l]^T [v-bar_l; a_l] (K = 2N): `stack[l]` is a [2N, in_l] buffer whose lower half receives
+    a_l during forward (straight from the previous layer's Softplus epilogue) and whose upper half receives
+    v-bar_l during backward; `ustack[l]` [2N, out_l] is filled the same way with u_l and z-bar_l."""
+
     @staticmethod
     def forward(ctx, e, skip_layer, beta_sp, thr_sp, beta_rho, *params):
         L = len(params) // 2
         Ws, bs = params[:L], params[L:]
         N, E = e.shape
+        new = lambda r, c: torch.empty((r, c), dtype=torch.float32, device=e.device)  # noqa: E731
+        stack = [new(2 * N, Ws[l].shape[1]) for l in range(L - 1)] + [None]     # the last layer is not stacked
+        lower = lambda l: stack[l][N:] if stack[l] is not None else None        # noqa: E731
         a_list, z_list = [], []
-        h = e
+        h = None
         for l in range(L):
-            a = torch.cat([h, e], 1) / _SQRT2 if l == skip_layer else h
-            if l < L - 1:    # z_l and h_{l+1} = softplus(z_l) from one kernel
-                z, h = gemm_ep(a, Ws[l], bs[l], False, True, EPI_SOFTPLUS, beta_sp, thr_sp)
+            if l == 0:
+                a = e if stack[0] is None else lower(0).copy_(e)
+            elif l == skip_layer:
+                a = torch.cat([h, e], 1, out=lower(l)).div_(_SQRT2) if stack[l] is not None \
+                    else torch.cat([h, e], 1) / _SQRT2
+            else:
+                a = h                                   # == lower(l) when the previous epilogue wrote it there
+            if l < L - 1:    # z_l and h_{l+1} = softplus(z_l) from one kernel; h goes where layer l+1 reads it
+                dst = lower(l + 1) if (l + 1 != skip_layer and stack[l + 1] is not None) else None
+                z, h = gemm_ep(a, Ws[l], bs[l], False, True, EPI_SOFTPLUS, beta_sp, thr_sp, out1=dst)
             else:
                 z = gemm(a, Ws[l], bs[l], False, True)
             a_list.append(a)
@@ -75,6 +91,7 @@ class _SdfMlp(torch.autograd.Function):
         g_e = v_list[0] if ge_skip is None else v_list[0] + ge_skip
 
         ctx.meta = (L, skip_layer, beta_sp, thr_sp, E)
+        ctx.stack = stack      # internal buffers (their lower halves are the saved a_l views)
         ctx.save_for_backward(e, sdf, c, denom, *Ws, *a_list, *z_list, *v_list)
         return out, g_e
 
@@ -88,10 +105,14 @@ class _SdfMlp(torch.autograd.Function):
         a_list = sv[4 + L:4 + 2 * L]
         z_list = sv[4 + 2 * L:4 + 3 * L]
         v_list = sv[4 + 3 * L:4 + 4 * L]
+        stack = ctx.stack
+        N = e.shape[0]
         need_w = ctx.needs_input_grad[5:5 + L]
+        new = lambda r, c_: torch.empty((r, c_), dtype=torch.float32, device=e.device)  # noqa: E731
         dW = [None] * L
         db = [None] * L
         zx = [None] * L       # extra z-bar from the adjoint of the gradient sweep
+        ustack = [None] * L   # [u_l; z-bar_l] of the layers whose weight gradient is one stacked GEMM
         s_extra = None
 
         # ---- adjoint of the gradient sweep (walks the layers upwards) --------------------------------------
@@ -99,14 +120,24 @@ class _SdfMlp(torch.autograd.Function):
             d_ge = d_ge.contiguous()
             vb_h = d_ge                                          # v-bar of layer 0 (hidden part)
             for l in range(L):
-                vb = torch.cat([vb_h, d_ge], 1) / _SQRT2 if l == skip_layer else vb_h
+                stacked = l < L - 1 and bool(need_w[l])
+                if l == skip_layer:
+                    vb = (torch.cat([vb_h, d_ge], 1, out=stack[l][:N]) if stacked else torch.cat([vb_h, d_ge], 1))
+                    vb = vb.div_(_SQRT2)
+                elif stacked and vb_h.data_ptr() != stack[l].data_ptr():
+                    vb = stack[l][:N].copy_(vb_h)                # (layer 0, or after an unstacked layer)
+                else:
+                    vb = vb_h
                 if l < L - 1:
                     # u-bar_l = v-bar_l W_l^T and, on its accumulators, the adjoint of u_l = v_{l+1}[:, :dh] * s1(z_l):
                     #   v-bar_{l+1} = u-bar * s1,  extra z-bar_l = u-bar * v_{l+1} * s2,  u_l itself (for W-bar_l)
-                    vb_h, zx[l], u = gemm_ep(vb, Ws[l], None, False, True, EPI_ADJOINT, beta_sp, thr_sp,
-                                             z=z_list[l], g=v_list[l + 1], want_out3=bool(need_w[l]))
-                    if need_w[l]:
-                        dW[l] = gemm(u, vb, None, True, False)   # W-bar_l = u_l^T v-bar_l
+                    if stacked:
+                        ustack[l] = new(2 * N, Ws[l].shape[0])
+                    nxt = l + 1
+                    dst = stack[nxt][:N] if (nxt < L - 1 and nxt != skip_layer and need_w[nxt]) else None
+                    vb_h, zx[l], _ = gemm_ep(vb, Ws[l], None, False, True, EPI_ADJOINT, beta_sp, thr_sp,
+                                             z=z_list[l], g=v_list[l + 1], out1=dst,
+                                             out3=ustack[l][:N] if stacked else None)
                 else:
                     w0 = Ws[l][0]                                # last layer: u = c * onehot(0)
                     cb = vb @ w0                                 # c-bar = u-bar[:, 0]
@@ -121,7 +152,9 @@ class _SdfMlp(torch.autograd.Function):
         de = None
         for l in range(L - 1, -1, -1):
             if need_w[l]:
-                if dW[l] is None:
+                if ustack[l] is not None:                        # zb IS ustack[l][N:] (written by layer l+1 below)
+                    dW[l] = gemm(ustack[l], stack[l], None, True, False)     # [u; z-bar]^T [v-bar; a], K = 2N
+                elif dW[l] is None:
                     dW[l] = gemm(zb, a_list[l], None, True, False)
                 else:
                     gemm(zb, a_list[l], None, True, False, out=dW[l], accumulate=True)
@@ -131,9 +164,10 @@ class _SdfMlp(torch.autograd.Function):
                 # a-bar_l = z-bar_l W_l; z-bar_{l-1} = a-bar_l[:, :dh] * s1(z_{l-1}) (+ the adjoint sweep's share)
                 dh = z_list[l - 1].shape[1]
                 is_skip = l == skip_layer
+                dst = ustack[l - 1][N:] if ustack[l - 1] is not None else None
                 ab, zb = gemm_ep(zb, Ws[l], None, False, False, EPI_S1MUL, beta_sp, thr_sp,
                                  scale=1.0 / _SQRT2 if is_skip else 1.0, z=z_list[l - 1], g=zx[l - 1], nz=dh,
-                                 want_c=is_skip)
+                                 want_c=is_skip, out1=dst)
                 if is_skip:
                     de = ab[:, dh:] if de is None else de + ab[:, dh:]
             else:

@@ -197,12 +197,13 @@ def _rowmajor(t):
 
 
 def gemm_ep(a, b, bias, trans_a, trans_b, mode, beta, thr, scale=1.0, z=None, g=None, nz=None, want_c=True,
-            want_out3=False):
+            want_out3=False, out1=None, out3=None):
     """GEMM with a fused Softplus epilogue (hm_gemm_f32_ep; include/hashmod.h).  v = (op(a) @ op(b) + bias) * scale.
       EPI_SOFTPLUS -> (v, softplus(v))
       EPI_S1MUL    -> (v or None, v[:, :nz] * s1(z) (+ g))
       EPI_ADJOINT  -> (v * s1(z), v * g * s2(z), g * s1(z) or None)
-    Row-major 2-D operands with arbitrary row strides (views of wider tensors are fine); no autograd."""
+    Row-major 2-D operands with arbitrary row strides (views of wider tensors are fine); no autograd.
+    out1 / out3: optional caller-owned destinations (row slices of larger buffers) for the first / third output."""
     require_gpu(a, b, bias, z, g)
     a, b = _rowmajor(a), _rowmajor(b)
     M, K = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
@@ -215,8 +216,15 @@ def gemm_ep(a, b, bias, trans_a, trans_b, mode, beta, thr, scale=1.0, z=None, g=
     ep.mode, ep.scale, ep.beta, ep.threshold = mode, float(scale), float(beta), float(thr)
     c = new(N) if (want_c or mode == EPI_SOFTPLUS) else None
     outs = ()
+    def dest(buf, cols):
+        if buf is None:
+            return new(cols)
+        if buf.shape != (M, cols) or buf.stride(1) != 1 or buf.dtype != torch.float32:
+            raise ValueError("hashmod gemm_ep: bad output buffer")
+        return buf
+
     if mode == EPI_SOFTPLUS:
-        o1 = new(N)
+        o1 = dest(out1, N)
         outs = (c, o1)
     else:
         z = _rowmajor(z)
@@ -228,12 +236,12 @@ def gemm_ep(a, b, bias, trans_a, trans_b, mode, beta, thr, scale=1.0, z=None, g=
         ep.z, ep.ldz = z.data_ptr(), z.stride(0)
         if g is not None:
             ep.g, ep.ldg = g.data_ptr(), g.stride(0)
-        o1 = new(ncol)
+        o1 = dest(out1, ncol)
         if mode == EPI_S1MUL:
             outs = (c, o1)
         else:
             o2 = new(N)
-            o3 = new(N) if want_out3 else None
+            o3 = dest(out3, N) if (want_out3 or out3 is not None) else None
             ep.out2, ep.ld2 = o2.data_ptr(), o2.stride(0)
             if o3 is not None:
                 ep.out3, ep.ld3 = o3.data_ptr(), o3.stride(0)
