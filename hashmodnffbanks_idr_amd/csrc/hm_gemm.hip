@@ -264,7 +264,8 @@ __global__ __launch_bounds__(128 * WM * KS, (WM * KS == 4 ? 4 : 1)) void gemm_f3
 // round trip of stage s+1 - store, the ONE barrier of the stage, fragment reads - is issued in the middle of stage
 // s's MFMAs.  (A wave that has passed the barrier of stage s has read the fragments of stage s-1's buffer long
 // before, so that buffer is free to refill.)  The loop body has NO conditionals - the host launches this kernel
-// only when every tile is interior and the K range is a whole number of kPipeD-stage groups - because with the
+// only when the K range is a whole number of kPipeD-stage groups, partial edge tiles clamp their row pointers once,
+// before the loop - because with the
 // generic kernel's guards in it hipcc keeps the accumulators in VGPRs across the back edge and copies all 32 of
 // them to AGPRs and back every stage.
 // AKC / BKC: operand is k-contiguous and 16-B aligned (one dwordx4 per k-group), else row-contiguous (four dwords).
@@ -319,10 +320,12 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int e = tid + NT * i;
-        pa[i] = AKC ? g.A + (int64_t)(m0 + e / KG) * g.lda + kbeg + (e % KG) * 4
-                    : g.A + (int64_t)(kbeg + (e / BM) * 4) * g.lda + m0 + e % BM;
-        pb[i] = BKC ? g.B + (int64_t)(n0 + e / KG) * g.ldb + kbeg + (e % KG) * 4
-                    : g.B + (int64_t)(kbeg + (e / BN) * 4) * g.ldb + n0 + e % BN;
+        // rows / columns past the edge of a partial tile are clamped HERE, once (they compute values nobody stores)
+        const int am = min(m0 + (AKC ? e / KG : e % BM), g.M - 1), bn = min(n0 + (BKC ? e / KG : e % BN), g.N - 1);
+        pa[i] = AKC ? g.A + (int64_t)am * g.lda + kbeg + (e % KG) * 4
+                    : g.A + (int64_t)(kbeg + (e / BM) * 4) * g.lda + am;
+        pb[i] = BKC ? g.B + (int64_t)bn * g.ldb + kbeg + (e % KG) * 4
+                    : g.B + (int64_t)(kbeg + (e / BN) * 4) * g.ldb + bn;
     }
     const int64_t sa = AKC ? BK : (int64_t)BK * g.lda, sb = BKC ? BK : (int64_t)BK * g.ldb;
     const int64_t lda = g.lda, ldb = g.ldb;
@@ -372,7 +375,8 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(GemmArgs g) {
 #undef HM_PIPE_FETCH
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
-    gemm_store_tile<EP>(g, acc, n0 + wn * 32 + j, m0 + wm * 32 + 4 * h, (g.bias != nullptr) && (blockIdx.z == 0));
+    const int n = n0 + wn * 32 + j;
+    if (n < g.N) gemm_store_tile<EP>(g, acc, n, m0 + wm * 32 + 4 * h, (g.bias != nullptr) && (blockIdx.z == 0));
 }
 
 // zero an M x N window of C (split-K accumulates with atomics); a plain kernel instead of
@@ -436,9 +440,9 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K, co
     const bool half_rows = !big && small_cfg == 0 && half_cfg != 0 && t64 >= 128 && t64 < 512 && M >= 256;
     const int64_t bm = big ? 128 : (half_rows ? 32 : 64), bn = big ? 128 : 64;
     static const int pipe_cfg = [] { const char *e = getenv("HM_GEMM_PIPE"); return e ? atoi(e) : 1; }();
-    // the pipelined kernel takes only regular problems: whole 64x64 tiles, K a whole number of 128-deep groups per
-    // split, operands either k-contiguous + 16-B aligned or row-contiguous
-    const bool use_pipe = !big && small_cfg == 0 && !half_rows && pipe_cfg != 0 && M % 64 == 0 && N % 64 == 0 &&
+    // the pipelined kernel takes K ranges that are a whole number of 128-deep groups per split and operands that are
+    // either k-contiguous + 16-B aligned or row-contiguous (partial edge tiles are fine: clamped rows, guarded stores)
+    const bool use_pipe = !big && small_cfg == 0 && !half_rows && pipe_cfg != 0 &&
                           K % (kPipeBK * kPipeD) == 0 && K > 0 && (!a_kc || g.vecA) && (!b_kc || g.vecB);
     const int64_t kBK = big ? 32 : (use_pipe ? kPipeBK * kPipeD : (small_cfg == 1 || small_cfg == 2 ? 64 : 128));
     const int64_t tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);

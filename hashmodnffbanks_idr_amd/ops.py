@@ -183,9 +183,8 @@ def gemm(a, b, bias=None, trans_a=False, trans_b=False, out=None, accumulate=Fal
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     if bias is not None:
         bias = bias.contiguous()
-    check(lib().hm_gemm_f32(int(trans_a), int(trans_b), M, N, K, dptr(a), max(a.stride(0), 1), dptr(b),
-                            max(b.stride(0), 1), dptr(bias), dptr(out), out.stride(0), int(accumulate),
-                            stream_ptr(a)))
+    check(lib().hm_gemm_f32(int(trans_a), int(trans_b), M, N, K, dptr(a), _ld(a), dptr(b), _ld(b), dptr(bias),
+                            dptr(out), _ld(out), int(accumulate), stream_ptr(a)))
     return out
 
 
@@ -194,6 +193,11 @@ EPI_SOFTPLUS, EPI_S1MUL, EPI_ADJOINT = 1, 2, 3
 
 def _rowmajor(t):
     return t if t.stride(-1) == 1 else t.contiguous()
+
+
+def _ld(t):
+    """row stride in elements; torch reports arbitrary strides for size-1 dimensions"""
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1], 1)
 
 
 def gemm_ep(a, b, bias, trans_a, trans_b, mode, beta, thr, scale=1.0, z=None, g=None, nz=None, want_c=True,
@@ -249,9 +253,8 @@ def gemm_ep(a, b, bias, trans_a, trans_b, mode, beta, thr, scale=1.0, z=None, g=
     ep.out1, ep.ld1 = o1.data_ptr(), o1.stride(0)
     if bias is not None:
         bias = bias.contiguous()
-    check(lib().hm_gemm_f32_ep(int(trans_a), int(trans_b), M, N, K, dptr(a), max(a.stride(0), 1), dptr(b),
-                               max(b.stride(0), 1), dptr(bias), dptr(c), c.stride(0) if c is not None else N,
-                               C.byref(ep), stream_ptr(a)))
+    check(lib().hm_gemm_f32_ep(int(trans_a), int(trans_b), M, N, K, dptr(a), _ld(a), dptr(b), _ld(b), dptr(bias),
+                               dptr(c), _ld(c) if c is not None else N, C.byref(ep), stream_ptr(a)))
     return outs
 
 
