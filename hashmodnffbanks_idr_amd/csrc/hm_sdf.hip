@@ -451,17 +451,21 @@ __device__ __forceinline__ void sdf_m16_body(const HmLevels &lv, const SdfNet &n
                             ring[(u + kRing16 - 1) % kRing16][2] = A[o2 + off];
                             ring[(u + kRing16 - 1) % kRing16][3] = A[o3 + off];
                         }
+                        // keep the four loads HERE: left to itself hipcc sinks them below this block's MFMAs (their
+                        // destination registers double as MFMA temporaries), which halves the bytes in flight
+                        __builtin_amdgcn_sched_barrier(0);
                         const float *src = (t < nb0) ? src0 + (4 * t + q) * kGroupFloats16
                                                      : src1 + (4 * (t - nb0) + q) * kGroupFloats16;
                         const float4 b = *reinterpret_cast<const float4 *>(src + j * 4);
+                        // component-major order: four INDEPENDENT accumulators between two uses of the same one
 #pragma unroll
-                        for (int a = 0; a < 4; ++a) {
-                            const float4 av = ring[u][a];
-                            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b.x, acc[a], 0, 0, 0);
-                            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b.y, acc[a], 0, 0, 0);
-                            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b.z, acc[a], 0, 0, 0);
-                            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b.w, acc[a], 0, 0, 0);
-                        }
+                        for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[u][a].x, b.x, acc[a], 0, 0, 0);
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[u][a].y, b.y, acc[a], 0, 0, 0);
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[u][a].z, b.z, acc[a], 0, 0, 0);
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[u][a].w, b.w, acc[a], 0, 0, 0);
                     }
                 }
             }
@@ -680,6 +684,9 @@ __device__ __forceinline__ void sdf_m8_body(const HmLevels &lv, const SdfNet &ne
                             ring[(u + RD8 - 1) % RD8][2] = A[o2 + off];
                             ring[(u + RD8 - 1) % RD8][3] = A[o3 + off];
                         }
+                        // keep the four loads HERE: left to itself hipcc sinks them below this block's MFMAs (their
+                        // destination registers double as MFMA temporaries), which halves the bytes in flight
+                        __builtin_amdgcn_sched_barrier(0);
                         const float *src = (t < nb0) ? src0 + (4 * t + q) * kGroupFloats8
                                                      : src1 + (4 * (t - nb0) + q) * kGroupFloats8;
                         const float4 b0 = *reinterpret_cast<const float4 *>(src + p4 * 4);
