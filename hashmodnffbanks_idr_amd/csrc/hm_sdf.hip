@@ -199,39 +199,48 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_kernel(HmLevels lv, Sd
                     r0[st] = A0[off];
                     r1[st] = A1[off];
                 }
-                for (int gg0 = 0; gg0 < n_oct; gg0 += 4) {
+                auto octet = [&](int gg, const float4 &a0, const float4 &a1) {
+                    const float *src = (gg < no0) ? src0 + (2 * gg + h) * kGroupFloats
+                                                  : src1 + (2 * (gg - no0) + h) * kGroupFloats;
+                    const float4 b0 = *reinterpret_cast<const float4 *>(src + j * 4);
+                    const float4 b1 = *reinterpret_cast<const float4 *>(src + (32 + j) * 4);
+                    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc00, 0, 0, 0);
+                    acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b1.x, acc01, 0, 0, 0);
+                    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, acc10, 0, 0, 0);
+                    acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc11, 0, 0, 0);
+                    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc00, 0, 0, 0);
+                    acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b1.y, acc01, 0, 0, 0);
+                    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b0.y, acc10, 0, 0, 0);
+                    acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc11, 0, 0, 0);
+                    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc00, 0, 0, 0);
+                    acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b1.z, acc01, 0, 0, 0);
+                    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b0.z, acc10, 0, 0, 0);
+                    acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, acc11, 0, 0, 0);
+                    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc00, 0, 0, 0);
+                    acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b1.w, acc01, 0, 0, 0);
+                    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b0.w, acc10, 0, 0, 0);
+                    acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc11, 0, 0, 0);
+                };
+                // whole groups of four octets run without an exit test: with a `break` inside the unrolled group
+                // hipcc cannot count the loads in flight across the back edge and drains them (vmcnt(0)) at every
+                // loop head; the 1-3 left-over octets are already in ring slots 0..2
+                const int n_full = n_oct & ~3;
+                for (int gg0 = 0; gg0 < n_full; gg0 += 4) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int gg = gg0 + u;
-                        if (gg >= n_oct) break;
                         {
                             const size_t off = (size_t)min(gg + 3, n_oct - 1) * 64;
                             r0[(u + 3) & 3] = A0[off];
                             r1[(u + 3) & 3] = A1[off];
                         }
-                        const float *src = (gg < no0) ? src0 + (2 * gg + h) * kGroupFloats
-                                                      : src1 + (2 * (gg - no0) + h) * kGroupFloats;
-                        const float4 b0 = *reinterpret_cast<const float4 *>(src + j * 4);
-                        const float4 b1 = *reinterpret_cast<const float4 *>(src + (32 + j) * 4);
-                        const float4 a0 = r0[u], a1 = r1[u];
-                        acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc00, 0, 0, 0);
-                        acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b1.x, acc01, 0, 0, 0);
-                        acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, acc10, 0, 0, 0);
-                        acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc11, 0, 0, 0);
-                        acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc00, 0, 0, 0);
-                        acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b1.y, acc01, 0, 0, 0);
-                        acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b0.y, acc10, 0, 0, 0);
-                        acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc11, 0, 0, 0);
-                        acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc00, 0, 0, 0);
-                        acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b1.z, acc01, 0, 0, 0);
-                        acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b0.z, acc10, 0, 0, 0);
-                        acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, acc11, 0, 0, 0);
-                        acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc00, 0, 0, 0);
-                        acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b1.w, acc01, 0, 0, 0);
-                        acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b0.w, acc10, 0, 0, 0);
-                        acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc11, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);   // (loads stay ahead of this octet's MFMAs; see the 16-point body)
+                        octet(gg, r0[u], r1[u]);
                     }
                 }
+                if (n_full + 0 < n_oct) octet(n_full + 0, r0[0], r1[0]);
+                if (n_full + 1 < n_oct) octet(n_full + 1, r0[1], r1[1]);
+                if (n_full + 2 < n_oct) octet(n_full + 2, r0[2], r1[2]);
             }
             __syncthreads();  // every wave has finished reading X / EMB for this layer
 
@@ -439,11 +448,28 @@ __device__ __forceinline__ void sdf_m16_body(const HmLevels &lv, const SdfNet &n
                 const float *src1 = (Ly.seg_src[1] == 0) ? X : EMB;
                 if (!ring_ready) prefetch16(li);
                 ring_ready = false;
-                for (int tt = 0; tt < nb; tt += kRing16) {
+                auto block16 = [&](int t, const float4 (&w)[4]) {
+                    const float *src = (t < nb0) ? src0 + (4 * t + q) * kGroupFloats16
+                                                 : src1 + (4 * (t - nb0) + q) * kGroupFloats16;
+                    const float4 b = *reinterpret_cast<const float4 *>(src + j * 4);
+                    // component-major order: four INDEPENDENT accumulators between two uses of the same one
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[a].x, b.x, acc[a], 0, 0, 0);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[a].y, b.y, acc[a], 0, 0, 0);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[a].z, b.z, acc[a], 0, 0, 0);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[a].w, b.w, acc[a], 0, 0, 0);
+                };
+                // whole groups of kRing16 blocks run without an exit test (with a `break` inside the unrolled group
+                // hipcc drains all loads in flight - vmcnt(0) - at every loop head); the left-over blocks are
+                // already in ring slots 0 .. kRing16-2
+                const int nb_full = (nb / kRing16) * kRing16;
+                for (int tt = 0; tt < nb_full; tt += kRing16) {
 #pragma unroll
                     for (int u = 0; u < kRing16; ++u) {
                         const int t = tt + u;
-                        if (t >= nb) break;
                         {
                             const size_t off = (size_t)min(t + kRing16 - 1, nb - 1) * 64;
                             ring[(u + kRing16 - 1) % kRing16][0] = A[off];
@@ -454,20 +480,12 @@ __device__ __forceinline__ void sdf_m16_body(const HmLevels &lv, const SdfNet &n
                         // keep the four loads HERE: left to itself hipcc sinks them below this block's MFMAs (their
                         // destination registers double as MFMA temporaries), which halves the bytes in flight
                         __builtin_amdgcn_sched_barrier(0);
-                        const float *src = (t < nb0) ? src0 + (4 * t + q) * kGroupFloats16
-                                                     : src1 + (4 * (t - nb0) + q) * kGroupFloats16;
-                        const float4 b = *reinterpret_cast<const float4 *>(src + j * 4);
-                        // component-major order: four INDEPENDENT accumulators between two uses of the same one
-#pragma unroll
-                        for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[u][a].x, b.x, acc[a], 0, 0, 0);
-#pragma unroll
-                        for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[u][a].y, b.y, acc[a], 0, 0, 0);
-#pragma unroll
-                        for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[u][a].z, b.z, acc[a], 0, 0, 0);
-#pragma unroll
-                        for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[u][a].w, b.w, acc[a], 0, 0, 0);
+                        block16(t, ring[u]);
                     }
                 }
+#pragma unroll
+                for (int u = 0; u < kRing16 - 1; ++u)
+                    if (nb_full + u < nb) block16(nb_full + u, ring[u]);
             }
             // request the next layer's first blocks now: they travel while this layer's epilogue and the two
             // barriers run (weights do not depend on the activations)
@@ -672,11 +690,29 @@ __device__ __forceinline__ void sdf_m8_body(const HmLevels &lv, const SdfNet &ne
                 const float *src1 = (Ly.seg_src[1] == 0) ? X : EMB;
                 if (!ring_ready) prefetch8(li);
                 ring_ready = false;
-                for (int tt = 0; tt < nb; tt += RD8) {
+                auto block8 = [&](int t, const float4 (&w)[4]) {
+                    const float *src = (t < nb0) ? src0 + (4 * t + q) * kGroupFloats8
+                                                 : src1 + (4 * (t - nb0) + q) * kGroupFloats8;
+                    const float4 b0 = *reinterpret_cast<const float4 *>(src + p4 * 4);
+                    const float4 b1 = TWO ? *reinterpret_cast<const float4 *>(src + (p4 + 4) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const float4 av = w[a];
+                        acc0[a] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.x, b0.x, acc0[a], 0, 0, 0);
+                        if (TWO) acc1[a] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.x, b1.x, acc1[a], 0, 0, 0);
+                        acc0[a] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.y, b0.y, acc0[a], 0, 0, 0);
+                        if (TWO) acc1[a] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.y, b1.y, acc1[a], 0, 0, 0);
+                        acc0[a] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.z, b0.z, acc0[a], 0, 0, 0);
+                        if (TWO) acc1[a] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.z, b1.z, acc1[a], 0, 0, 0);
+                        acc0[a] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.w, b0.w, acc0[a], 0, 0, 0);
+                        if (TWO) acc1[a] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.w, b1.w, acc1[a], 0, 0, 0);
+                    }
+                };
+                const int nb_full = (nb / RD8) * RD8;   // (no exit test inside the unrolled group: see the 16-point body)
+                for (int tt = 0; tt < nb_full; tt += RD8) {
 #pragma unroll
                     for (int u = 0; u < RD8; ++u) {
                         const int t = tt + u;
-                        if (t >= nb) break;
                         {
                             const size_t off = (size_t)min(t + RD8 - 1, nb - 1) * 64;
                             ring[(u + RD8 - 1) % RD8][0] = A[off];
@@ -684,27 +720,13 @@ __device__ __forceinline__ void sdf_m8_body(const HmLevels &lv, const SdfNet &ne
                             ring[(u + RD8 - 1) % RD8][2] = A[o2 + off];
                             ring[(u + RD8 - 1) % RD8][3] = A[o3 + off];
                         }
-                        // keep the four loads HERE: left to itself hipcc sinks them below this block's MFMAs (their
-                        // destination registers double as MFMA temporaries), which halves the bytes in flight
-                        __builtin_amdgcn_sched_barrier(0);
-                        const float *src = (t < nb0) ? src0 + (4 * t + q) * kGroupFloats8
-                                                     : src1 + (4 * (t - nb0) + q) * kGroupFloats8;
-                        const float4 b0 = *reinterpret_cast<const float4 *>(src + p4 * 4);
-                        const float4 b1 = TWO ? *reinterpret_cast<const float4 *>(src + (p4 + 4) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                        for (int a = 0; a < 4; ++a) {
-                            const float4 av = ring[u][a];
-                            acc0[a] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.x, b0.x, acc0[a], 0, 0, 0);
-                            if (TWO) acc1[a] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.x, b1.x, acc1[a], 0, 0, 0);
-                            acc0[a] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.y, b0.y, acc0[a], 0, 0, 0);
-                            if (TWO) acc1[a] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.y, b1.y, acc1[a], 0, 0, 0);
-                            acc0[a] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.z, b0.z, acc0[a], 0, 0, 0);
-                            if (TWO) acc1[a] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.z, b1.z, acc1[a], 0, 0, 0);
-                            acc0[a] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.w, b0.w, acc0[a], 0, 0, 0);
-                            if (TWO) acc1[a] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.w, b1.w, acc1[a], 0, 0, 0);
-                        }
+                        __builtin_amdgcn_sched_barrier(0);   // loads stay ahead of this block's MFMAs
+                        block8(t, ring[u]);
                     }
                 }
+#pragma unroll
+                for (int u = 0; u < RD8 - 1; ++u)
+                    if (nb_full + u < nb) block8(nb_full + u, ring[u]);
             }
             if (li + 1 < net.n_layers && !(li + 1 == net.n_layers - 1 && out_cols == 1)) {
                 if (2 * net.layer[li + 1].n_tiles - 4 * wave > 0) {
