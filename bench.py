@@ -214,7 +214,7 @@ def cpu_baseline(model, n_rays=256, reps=2):
 
     # thread sweep on the same sample: with ~2000 small ops per step the all-core setting is not the fastest one
     sweep = []
-    for nt in sorted({cores, min(cores, 16)}, reverse=True):
+    for nt in sorted({cores, min(cores, 32), min(cores, 16), min(cores, 8)}, reverse=True):
         torch.set_num_threads(nt)
         one()
         t0 = time.perf_counter()
