@@ -17,6 +17,9 @@
 //   * the accumulator tile has the point on the lane and 4 consecutive features per register
 //     quad, i.e. exactly one 16-B k-group of the NEXT layer: the epilogue (bias, Softplus(100),
 //     optional /sqrt(2)) writes it back with ds_write_b128 - no transpose, no shuffles.
+// Small batches (the ray search issues ~30 dependent calls of 1...4096 points per iteration) use 16-, 8- and
+// 4-point tiles so that every call is ONE tile per CU; the tile size is chosen on the device from the live
+// point count (sdf_fwd_small_kernel -> sdf_m16_body / sdf_m8_body<8|4>).
 #include "hm_common.h"
 
 #include <math.h>
@@ -875,7 +878,7 @@ int hm_sdf_fwd(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *x,
                  "hm_sdf_fwd: tile_points 4 / 8 / 16 need w_packed_m16 in every layer");
     if (n == 0) return HM_OK;
     HM_CHECK_ARG(x && table && B_fourier && out, "hm_sdf_fwd: NULL pointer");
-    // small batches: 16-point tiles spread the call over the whole chip (see sdf_fwd_m16_kernel).
+    // small batches: 16-point tiles spread the call over the whole chip (see sdf_m16_body / sdf_m8_body).
     // With a device-side count the host cannot know the batch size: both kernels are enqueued and
     // each returns at once unless the live count falls in its range.
     constexpr int64_t kSmall = 8192;
