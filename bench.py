@@ -60,10 +60,14 @@ class Conf(dict):
         return Conf(v) if v is not None else None
 
 
+# measurement-only configurations (not golden-pinned): C2's level structure with every table L2-resident
+EXTRA_CONFIGS = {"C2_l2": (16, 15, 16, 512)}
+
+
 def idr_conf(cfg):
     """confs/embedder_conf_var/MultiResHashPointsAndViewDirs/dtu_fixed_cameras.conf with the
     embedding_network block of BASELINE.json's config."""
-    L, T, b, d = P.CONFIGS[cfg]
+    L, T, b, d = P.CONFIGS[cfg] if cfg in P.CONFIGS else EXTRA_CONFIGS[cfg]
     return Conf(
         feature_vector_size=256,
         implicit_network=dict(d_in=3, d_out=1, dims=[512] * 8, geometric_init=True, bias=0.6, skip_in=[4],

@@ -40,7 +40,6 @@ CONFIGS = {
     "shipped": (6, 5, 8, 512),
     "viewdir": (4, 3, 16, 512),
     "tiny": (4, 8, 4, 32),
-    "C2_l2": (16, 15, 16, 512),   # C2's level structure with every table L2-resident (gather ceiling experiment)
 }
 
 
