@@ -35,6 +35,7 @@ SIGNATURES = {
     "hm_pack_mlp_layer": (_int, [_p, _i64, _p, _int, _int, _int, _p, _p, _p, _p]),
     "hm_softplus": (_int, [_int, _p, _p, _p, _p, _p, _i64, C.c_float, C.c_float, _p]),
     "hm_colsum": (_int, [_p, _i64, _i64, _i64, _p, _p]),
+    "hm_colsum_acc": (_int, [_p, _i64, _i64, _i64, _p, _p]),
     "hm_idr_loss": (_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, C.c_float, C.c_float, C.c_float, _p, _p, _p, _p, _p]),
     "hm_adam_step": (_int, [_p, _int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _p, _p]),
     "hm_gemm_f32_ep": (_int, [_int, _int, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _p]),

@@ -120,12 +120,12 @@ int hm_softplus(int order, const float *z, const float *gy, const float *gg, flo
     return HM_OK;
 }
 
-int hm_colsum(const float *x, int64_t M, int64_t N, int64_t ld, float *out, void *stream) {
+static int colsum_impl(const float *x, int64_t M, int64_t N, int64_t ld, float *out, bool zero_first, void *stream) {
     HM_CHECK_ARG(M >= 0 && N >= 0 && ld >= N, "hm_colsum: bad shape");
     if (N == 0) return HM_OK;
     HM_CHECK_ARG(out != nullptr, "hm_colsum: out is NULL");
     hipStream_t st = as_stream(stream);
-    hm_zero_u32_async(out, N, st);
+    if (zero_first) hm_zero_u32_async(out, N, st);
     if (M == 0) return HM_OK;
     HM_CHECK_ARG(x != nullptr, "hm_colsum: x is NULL");
     int rows = 32;
@@ -135,6 +135,14 @@ int hm_colsum(const float *x, int64_t M, int64_t N, int64_t ld, float *out, void
                        ld, out, rows);
     HM_CHECK_LAUNCH("hm_colsum");
     return HM_OK;
+}
+
+int hm_colsum(const float *x, int64_t M, int64_t N, int64_t ld, float *out, void *stream) {
+    return colsum_impl(x, M, N, ld, out, true, stream);
+}
+
+int hm_colsum_acc(const float *x, int64_t M, int64_t N, int64_t ld, float *out, void *stream) {
+    return colsum_impl(x, M, N, ld, out, false, stream);
 }
 
 }  // extern "C"

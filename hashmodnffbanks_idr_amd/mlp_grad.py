@@ -23,7 +23,7 @@ import math
 import torch
 
 from . import ops
-from .ops import EPI_ADJOINT, EPI_S1MUL, EPI_SOFTPLUS, _softplus_call, colsum, gemm, gemm_ep
+from .ops import EPI_ADJOINT, EPI_S1MUL, EPI_SOFTPLUS, _softplus_call, colsum_into, gemm, gemm_ep
 
 _SQRT2 = math.sqrt(2.0)
 
@@ -109,8 +109,15 @@ class _SdfMlp(torch.autograd.Function):
         N = e.shape[0]
         need_w = ctx.needs_input_grad[5:5 + L]
         new = lambda r, c_: torch.empty((r, c_), dtype=torch.float32, device=e.device)  # noqa: E731
-        dW = [None] * L
-        db = [None] * L
+        # every weight / bias gradient accumulates with atomics (split-K GEMMs, column sums): the buffers are zeroed
+        # here by ONE multi-tensor launch instead of one zeroing launch in front of each producer
+        need_b = ctx.needs_input_grad[5 + L:5 + 2 * L]
+        bshape = [z.shape[1] for z in z_list]
+        dW = [torch.empty_like(Ws[l]) if need_w[l] else None for l in range(L)]
+        db = [torch.empty(bshape[l], dtype=torch.float32, device=e.device) if need_b[l] else None for l in range(L)]
+        zero_list = [t for t in dW + db if t is not None]
+        if zero_list:
+            torch._foreach_zero_(zero_list)
         zx = [None] * L       # extra z-bar from the adjoint of the gradient sweep
         ustack = [None] * L   # [u_l; z-bar_l] of the layers whose weight gradient is one stacked GEMM
         s_extra = None
@@ -142,7 +149,6 @@ class _SdfMlp(torch.autograd.Function):
                     w0 = Ws[l][0]                                # last layer: u = c * onehot(0)
                     cb = vb @ w0                                 # c-bar = u-bar[:, 0]
                     if need_w[l]:
-                        dW[l] = torch.zeros_like(Ws[l])
                         dW[l][0] = c @ vb
                     s_extra = cb * (-2.0 * sdf * c / denom)
 
@@ -153,13 +159,11 @@ class _SdfMlp(torch.autograd.Function):
         for l in range(L - 1, -1, -1):
             if need_w[l]:
                 if ustack[l] is not None:                        # zb IS ustack[l][N:] (written by layer l+1 below)
-                    dW[l] = gemm(ustack[l], stack[l], None, True, False)     # [u; z-bar]^T [v-bar; a], K = 2N
-                elif dW[l] is None:
-                    dW[l] = gemm(zb, a_list[l], None, True, False)
+                    gemm(ustack[l], stack[l], None, True, False, out=dW[l], accumulate=True)   # [u; z-bar]^T [v-bar; a]
                 else:
                     gemm(zb, a_list[l], None, True, False, out=dW[l], accumulate=True)
-            if ctx.needs_input_grad[5 + L + l]:
-                db[l] = colsum(zb)
+            if need_b[l]:
+                colsum_into(zb, db[l])
             if l > 0:
                 # a-bar_l = z-bar_l W_l; z-bar_{l-1} = a-bar_l[:, :dh] * s1(z_{l-1}) (+ the adjoint sweep's share)
                 dh = z_list[l - 1].shape[1]

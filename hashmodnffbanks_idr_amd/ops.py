@@ -451,6 +451,14 @@ def colsum(x):
     return _ColSum.apply(x)
 
 
+def colsum_into(x, out):
+    """out += column sums of x (no autograd; `out` zeroed by the caller)."""
+    require_gpu(x, out)
+    x = _rowmajor(x)
+    check(lib().hm_colsum_acc(dptr(x), x.shape[0], x.shape[1], _ld(x), dptr(out), stream_ptr(x)))
+    return out
+
+
 def _softplus_call(order, z, gy, gg, beta, thr):
     n = z.numel()
     out0 = torch.empty_like(z)

@@ -229,6 +229,8 @@ HM_API int hm_softplus(int order, const float *z, const float *gy, const float *
 
 /* out[n] = sum over rows of x[M,N] (row stride ld) - the bias gradient of an nn.Linear.          */
 HM_API int hm_colsum(const float *x, int64_t M, int64_t N, int64_t ld, float *out, void *stream);
+/* same, added into out (no zeroing: the caller zeroes all its gradient buffers with one launch)  */
+HM_API int hm_colsum_acc(const float *x, int64_t M, int64_t N, int64_t ld, float *out, void *stream);
 
 /* ---- IDRLoss: value and gradients in one launch (code/model/loss.py:4-70) --------------------------
  * terms[4] = {loss, rgb_loss, eikonal_loss, mask_loss};  d_rgb[n,3], d_sdf[n], d_grad[m,3] = d loss / d input.
