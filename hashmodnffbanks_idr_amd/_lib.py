@@ -34,6 +34,7 @@ SIGNATURES = {
                                 _i64, _p, _p]),
     "hm_pack_mlp_layer": (_int, [_p, _i64, _p, _int, _int, _int, _p, _p, _p, _p]),
     "hm_softplus": (_int, [_int, _p, _p, _p, _p, _p, _i64, C.c_float, C.c_float, _p]),
+    "hm_sdf_head": (_int, [_int, _p, _i64, _i64, C.c_float, _p, _p, _p, _p, _p, _p]),
     "hm_colsum": (_int, [_p, _i64, _i64, _i64, _p, _p]),
     "hm_colsum_acc": (_int, [_p, _i64, _i64, _i64, _p, _p]),
     "hm_idr_loss": (_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, C.c_float, C.c_float, C.c_float, _p, _p, _p, _p, _p]),

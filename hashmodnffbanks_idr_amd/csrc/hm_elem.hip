@@ -89,6 +89,49 @@ __global__ __launch_bounds__(kET) void colsum_kernel(const float *__restrict__ x
     atomicAdd(out + n, ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7)));
 }
 
+
+// ---- soft clamp of the SDF column (implicit_differentiable_renderer.py:112, density_net.py:20-30) ----------------
+// forward: out = zL with column 0 replaced by sdf = tanh(s / (2 + rho(s))), rho under no_grad;
+//          c = d sdf / d s = (1 - sdf^2) / (2 + rho), denom = 2 + rho  (what the gradient sweeps reuse)
+__global__ __launch_bounds__(kET) void sdf_head_fwd_kernel(const float *__restrict__ zl, int64_t n, int64_t cols,
+                                                           float beta_rho, float *__restrict__ out,
+                                                           float *__restrict__ sdf, float *__restrict__ c,
+                                                           float *__restrict__ denom) {
+    const int64_t i = (int64_t)blockIdx.x * kET + threadIdx.x;
+    if (i >= n * cols) return;
+    const int64_t row = i / cols, col = i - row * cols;
+    float v = zl[i];
+    if (col == 0) {
+        const float s = v;
+        const float sg = (s > 0.0f) ? 1.0f : ((s < 0.0f) ? -1.0f : 0.0f);
+        const float rho = (1.0f / beta_rho) * (0.5f + 0.5f * sg * expm1f(-fabsf(s) / beta_rho));
+        const float d = 2.0f + rho;
+        const float t = tanhf(s / d);
+        sdf[row] = t;
+        denom[row] = d;
+        c[row] = (1.0f - t * t) / d;
+        v = t;
+    }
+    out[i] = v;
+}
+
+// backward: zb = d_out with column 0 replaced by d_out[:,0] * c (+ cb * (-2 sdf c / denom), the share of the
+// gradient sweep's adjoint, cb = c-bar; NULL when no gradient flows through d sdf / d x)
+__global__ __launch_bounds__(kET) void sdf_head_bwd_kernel(const float *__restrict__ d_out, int64_t n, int64_t cols,
+                                                           const float *__restrict__ sdf, const float *__restrict__ c,
+                                                           const float *__restrict__ denom, const float *__restrict__ cb,
+                                                           float *__restrict__ zb) {
+    const int64_t i = (int64_t)blockIdx.x * kET + threadIdx.x;
+    if (i >= n * cols) return;
+    const int64_t row = i / cols, col = i - row * cols;
+    float v = d_out[i];
+    if (col == 0) {
+        v = v * c[row];
+        if (cb) v += cb[row] * (-2.0f * sdf[row] * c[row] / denom[row]);
+    }
+    zb[i] = v;
+}
+
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 }  // namespace
@@ -117,6 +160,23 @@ int hm_softplus(int order, const float *z, const float *gy, const float *gg, flo
                            threshold);
     }
     HM_CHECK_LAUNCH("hm_softplus");
+    return HM_OK;
+}
+
+int hm_sdf_head(int backward, const float *in, int64_t n, int64_t cols, float beta_rho, float *out, float *sdf,
+                float *c, float *denom, const float *cb, void *stream) {
+    HM_CHECK_ARG(n >= 0 && cols >= 1, "hm_sdf_head: bad shape");
+    if (n == 0) return HM_OK;
+    HM_CHECK_ARG(in && out && sdf && c && denom, "hm_sdf_head: NULL pointer");
+    HM_CHECK_ARG(backward || beta_rho > 0.0f, "hm_sdf_head: beta must be positive");
+    const unsigned grid = (unsigned)((n * cols + kET - 1) / kET);
+    if (!backward)
+        hipLaunchKernelGGL(sdf_head_fwd_kernel, dim3(grid), dim3(kET), 0, as_stream(stream), in, n, cols, beta_rho, out,
+                           sdf, c, denom);
+    else
+        hipLaunchKernelGGL(sdf_head_bwd_kernel, dim3(grid), dim3(kET), 0, as_stream(stream), in, n, cols, sdf, c, denom,
+                           cb, out);
+    HM_CHECK_LAUNCH("hm_sdf_head");
     return HM_OK;
 }
 

@@ -60,13 +60,7 @@ class _SdfMlp(torch.autograd.Function):
                 z = gemm(a, Ws[l], bs[l], False, True)
             a_list.append(a)
             z_list.append(z)
-        zL = z_list[-1]
-        s = zL[:, 0]
-        rho = (1.0 / beta_rho) * (0.5 + 0.5 * s.sign() * torch.expm1(-s.abs() / beta_rho))
-        denom = 2.0 + rho
-        sdf = torch.tanh(s / denom)
-        c = (1.0 - sdf * sdf) / denom
-        out = torch.cat([sdf.unsqueeze(-1), zL[:, 1:]], -1)
+        out, sdf, c, denom = ops.sdf_head_fwd(z_list[-1], beta_rho)     # soft clamp of column 0, one launch
 
         # reverse sweep for g_e = d sdf / d e: v_l = u_l W_l (scaled at the skip), u_{l-1} = v_l[:, :dh] * s1(z_{l-1})
         # - the product with s1 is the epilogue of the GEMM that makes v_l
@@ -120,7 +114,7 @@ class _SdfMlp(torch.autograd.Function):
             torch._foreach_zero_(zero_list)
         zx = [None] * L       # extra z-bar from the adjoint of the gradient sweep
         ustack = [None] * L   # [u_l; z-bar_l] of the layers whose weight gradient is one stacked GEMM
-        s_extra = None
+        cb = None
 
         # ---- adjoint of the gradient sweep (walks the layers upwards) --------------------------------------
         if d_ge is not None:
@@ -150,11 +144,9 @@ class _SdfMlp(torch.autograd.Function):
                     cb = vb @ w0                                 # c-bar = u-bar[:, 0]
                     if need_w[l]:
                         dW[l][0] = c @ vb
-                    s_extra = cb * (-2.0 * sdf * c / denom)
 
         # ---- backward of the forward sweep (walks the layers downwards) ------------------------------------
-        zb = d_out.clone()
-        zb[:, 0] = d_out[:, 0] * c if s_extra is None else d_out[:, 0] * c + s_extra
+        zb = ops.sdf_head_bwd(d_out, sdf, c, denom, cb)
         de = None
         for l in range(L - 1, -1, -1):
             if need_w[l]:

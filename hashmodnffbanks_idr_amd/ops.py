@@ -451,6 +451,30 @@ def colsum(x):
     return _ColSum.apply(x)
 
 
+def sdf_head_fwd(zl, beta_rho):
+    """(out, sdf, c, denom) of the soft SDF clamp (hm_sdf_head; no autograd)."""
+    require_gpu(zl)
+    zl = zl.contiguous()
+    n, cols = zl.shape
+    out = torch.empty_like(zl)
+    sdf, c, denom = (torch.empty(n, dtype=torch.float32, device=zl.device) for _ in range(3))
+    check(lib().hm_sdf_head(0, dptr(zl), n, cols, float(beta_rho), dptr(out), dptr(sdf), dptr(c), dptr(denom),
+                            None, stream_ptr(zl)))
+    return out, sdf, c, denom
+
+
+def sdf_head_bwd(d_out, sdf, c, denom, cb=None):
+    """z-bar of the last layer from d_out (and the gradient sweep's c-bar, if any)."""
+    require_gpu(d_out, cb)
+    d_out = d_out.contiguous()
+    n, cols = d_out.shape
+    zb = torch.empty_like(d_out)
+    cbp = cb.contiguous() if cb is not None else None
+    check(lib().hm_sdf_head(1, dptr(d_out), n, cols, 1.0, dptr(zb), dptr(sdf), dptr(c), dptr(denom), dptr(cbp),
+                            stream_ptr(d_out)))
+    return zb
+
+
 def colsum_into(x, out):
     """out += column sums of x (no autograd; `out` zeroed by the caller)."""
     require_gpu(x, out)

@@ -227,6 +227,14 @@ HM_API int hm_gemm_f32_ep(int transA, int transB, int64_t M, int64_t N, int64_t 
 HM_API int hm_softplus(int order, const float *z, const float *gy, const float *gg, float *out0, float *out1,
                        int64_t n, float beta, float threshold, void *stream);
 
+/* Soft clamp of the SDF column of the last layer's output zL [n, cols] (contiguous) and its backward
+ * (implicit_differentiable_renderer.py:112, density_net.py:20-30; the density is evaluated without gradient):
+ *   backward == 0:  out = zL with column 0 -> sdf = tanh(s / (2 + rho(s)));  sdf, denom = 2 + rho, c = d sdf/d s [n]
+ *   backward != 0:  out = d_out with column 0 -> d_out[:,0] * c (+ cb * (-2 sdf c / denom) when cb != NULL);
+ *                   sdf, c, denom are inputs here.                                                       */
+HM_API int hm_sdf_head(int backward, const float *in, int64_t n, int64_t cols, float beta_rho, float *out, float *sdf,
+                       float *c, float *denom, const float *cb, void *stream);
+
 /* out[n] = sum over rows of x[M,N] (row stride ld) - the bias gradient of an nn.Linear.          */
 HM_API int hm_colsum(const float *x, int64_t M, int64_t N, int64_t ld, float *out, void *stream);
 /* same, added into out (no zeroing: the caller zeroes all its gradient buffers with one launch)  */
