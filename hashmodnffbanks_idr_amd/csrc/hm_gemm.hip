@@ -379,6 +379,96 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(GemmArgs g) {
     if (n < g.N) gemm_store_tile<EP>(g, acc, n, m0 + wm * 32 + 4 * h, (g.bias != nullptr) && (blockIdx.z == 0));
 }
 
+// Same pipeline with EIGHT waves: two wave groups split the octets of every stage (two waves per SIMD hide each
+// other's barrier / LDS turnarounds), partial tiles are summed through LDS at the end.
+template <bool AKC, bool BKC, bool EP>
+__global__ __launch_bounds__(512, 4) void gemm_f32_pipe2_kernel(GemmArgs g) {
+    constexpr int BM = 64, BN = 64, BK = kPipeBK, NT = 512, PER = BM * BK / 4 / NT, KG = BK / 4, OCT = BK / 8 / 2;   // OCT: octets of a stage per wave group
+    __shared__ __align__(16) float As[2][BK * BM];
+    __shared__ __align__(16) float Bs[2][BK * BN];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int kpart = wave >> 2, wsub = wave & 3;   // two wave groups split the octets of every stage
+    const int wm = wsub >> 1, wn = wsub & 1;
+    const int j = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int kbeg = blockIdx.z * g.k_chunk;
+    const int stages = g.k_chunk / BK;   // multiple of kPipeD (host)
+
+    const float *pa[PER], *pb[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int e = tid + NT * i;
+        // rows / columns past the edge of a partial tile are clamped HERE, once (they compute values nobody stores)
+        const int am = min(m0 + (AKC ? e / KG : e % BM), g.M - 1), bn = min(n0 + (BKC ? e / KG : e % BN), g.N - 1);
+        pa[i] = AKC ? g.A + (int64_t)am * g.lda + kbeg + (e % KG) * 4
+                    : g.A + (int64_t)(kbeg + (e / BM) * 4) * g.lda + am;
+        pb[i] = BKC ? g.B + (int64_t)bn * g.ldb + kbeg + (e % KG) * 4
+                    : g.B + (int64_t)(kbeg + (e / BN) * 4) * g.ldb + bn;
+    }
+    const int64_t sa = AKC ? BK : (int64_t)BK * g.lda, sb = BKC ? BK : (int64_t)BK * g.ldb;
+    const int64_t lda = g.lda, ldb = g.ldb;
+    f32x16 acc, acc2;   // even / odd k-octets: two independent MFMA chains for the one wave on each SIMD
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = acc2[r] = 0.0f;
+    // the four ring slots and the two operand sets are separate named arrays (an array indexed by (u+3)%4 inside
+    // the unrolled loop was demoted to scratch memory by hipcc)
+    static_assert(kPipeD == 4, "the stage macro below is written out for a 4-deep ring (8-deep measured no faster)");
+    float4 ra0[PER], ra1[PER], ra2[PER], ra3[PER], rb0[PER], rb1[PER], rb2[PER], rb3[PER];
+    float4 opa0[OCT], opa1[OCT], opb0[OCT], opb1[OCT];
+#define HM_PIPE_FETCH(S_, RA_, RB_)                                                                 \
+    do {                                                                                            \
+        const int sc_ = min((S_), stages - 1); /* past the end: re-read the last stage, never multiplied */ \
+        pipe_fetch<AKC, PER>(pa, sa, lda, sc_, RA_);                                                \
+        pipe_fetch<BKC, PER>(pb, sb, ldb, sc_, RB_);                                                \
+    } while (0)
+    HM_PIPE_FETCH(0, ra0, rb0);
+    HM_PIPE_FETCH(1, ra1, rb1);
+    HM_PIPE_FETCH(2, ra2, rb2);
+    store_tile<BM, BK, NT>(As[0], AKC, tid, ra0);
+    store_tile<BN, BK, NT>(Bs[0], BKC, tid, rb0);
+    __syncthreads();
+    pipe_read_ops<OCT>(As[0], Bs[0], wm * 32 + j, wn * 32 + j, h + 4 * kpart, opa0, opb0);
+// one stage: multiply from operand set C, meanwhile fetch stage s+D-1 into ring slot F and move ring slot N (stage
+// s+1) through LDS buffer NB into operand set X
+#define HM_PIPE_STAGE(S_, F_, N_, C_, X_, NB_)                                                      \
+    do {                                                                                            \
+        HM_PIPE_FETCH((S_) + kPipeD - 1, ra##F_, rb##F_);                                                    \
+        pipe_mfma_oct(opa##C_[0], opb##C_[0], acc);                                                 \
+        store_tile<BM, BK, NT>(As[NB_], AKC, tid, ra##N_);                                          \
+        store_tile<BN, BK, NT>(Bs[NB_], BKC, tid, rb##N_);                                          \
+        __syncthreads();                                                                            \
+        pipe_read_ops<OCT>(As[NB_], Bs[NB_], wm * 32 + j, wn * 32 + j, h + 4 * kpart, opa##X_, opb##X_);        \
+        pipe_mfma_oct(opa##C_[1], opb##C_[1], acc2);                                                \
+    } while (0)
+    static_assert(OCT == 2, "HM_PIPE_STAGE is written for 2 octets per stage and wave group");
+    for (int s0 = 0; s0 < stages; s0 += kPipeD) {
+        HM_PIPE_STAGE(s0 + 0, 3, 1, 0, 1, 1);
+        HM_PIPE_STAGE(s0 + 1, 0, 2, 1, 0, 0);
+        HM_PIPE_STAGE(s0 + 2, 1, 3, 0, 1, 1);
+        HM_PIPE_STAGE(s0 + 3, 2, 0, 1, 0, 0);
+    }
+#undef HM_PIPE_STAGE
+#undef HM_PIPE_FETCH
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
+    {   // add the second wave group's partial tile (through the staging buffers, free now)
+        __syncthreads();
+        float *red = &As[0][0];   // 4 waves * 16 registers * 64 lanes floats == 2 * BK * BM
+        static_assert(2 * BK * BM >= 4 * 16 * 64, "reduction buffer");
+        if (kpart == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(wsub * 16 + r) * 64 + lane] = acc[r];
+        }
+        __syncthreads();
+        if (kpart == 1) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += red[(wsub * 16 + r) * 64 + lane];
+    }
+    const int n = n0 + wn * 32 + j;
+    if (n < g.N) gemm_store_tile<EP>(g, acc, n, m0 + wm * 32 + 4 * h, (g.bias != nullptr) && (blockIdx.z == 0));
+}
+
 // zero an M x N window of C (split-K accumulates with atomics); a plain kernel instead of
 // hipMemset2DAsync so that the call can be recorded into a HIP graph on every ROCm version
 __global__ __launch_bounds__(256) void zero_window_kernel(float *C, int64_t ldc, int64_t M, int64_t N) {
@@ -439,7 +529,7 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K, co
     static const int half_cfg = [] { const char *e = getenv("HM_GEMM_HALF"); return e ? atoi(e) : 0; }();
     const bool half_rows = !big && small_cfg == 0 && half_cfg != 0 && t64 >= 128 && t64 < 512 && M >= 256;
     const int64_t bm = big ? 128 : (half_rows ? 32 : 64), bn = big ? 128 : 64;
-    static const int pipe_cfg = [] { const char *e = getenv("HM_GEMM_PIPE"); return e ? atoi(e) : 1; }();
+    static const int pipe_cfg = [] { const char *e = getenv("HM_GEMM_PIPE"); return e ? atoi(e) : 2; }();   // 2 = eight-wave variant
     // the pipelined kernel takes K ranges that are a whole number of 128-deep groups per split and operands that are
     // either k-contiguous + 16-B aligned or row-contiguous (partial edge tiles are fine: clamped rows, guarded stores)
     const bool use_pipe = !big && small_cfg == 0 && !half_rows && pipe_cfg != 0 &&
@@ -500,7 +590,12 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K, co
     else if (pipe_ok) {
 #define HM_PIPE_LAUNCH(AKC_, BKC_)                                                                                \
     do {                                                                                                          \
-        if (g.ep.mode != HM_EPI_NONE)                                                                             \
+        if (pipe_cfg == 2) {                                                                                      \
+            if (g.ep.mode != HM_EPI_NONE)                                                                         \
+                hipLaunchKernelGGL((gemm_f32_pipe2_kernel<AKC_, BKC_, true>), grid, dim3(512), 0, st, g);         \
+            else                                                                                                  \
+                hipLaunchKernelGGL((gemm_f32_pipe2_kernel<AKC_, BKC_, false>), grid, dim3(512), 0, st, g);        \
+        } else if (g.ep.mode != HM_EPI_NONE)                                                                      \
             hipLaunchKernelGGL((gemm_f32_pipe_kernel<AKC_, BKC_, true>), grid, dim3(256), 0, st, g);              \
         else                                                                                                      \
             hipLaunchKernelGGL((gemm_f32_pipe_kernel<AKC_, BKC_, false>), grid, dim3(256), 0, st, g);             \
