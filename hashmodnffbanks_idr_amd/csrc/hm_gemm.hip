@@ -108,8 +108,8 @@ __device__ __forceinline__ void gemm_store_tile(const GemmArgs &g, const f32x16 
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
     float zv[8], gv[8];
-    if (mode >= HM_EPI_S1MUL) {
-        const int nc = mode == HM_EPI_S1MUL ? min(n, g.ep.nz - 1) : n;
+    if (mode == HM_EPI_S1MUL || mode == HM_EPI_ADJOINT || mode == HM_EPI_RELUMASK) {
+        const int nc = mode != HM_EPI_ADJOINT ? min(n, g.ep.nz - 1) : n;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int r = 8 * half + q;
@@ -144,6 +144,10 @@ __device__ __forceinline__ void gemm_store_tile(const GemmArgs &g, const f32x16 
         }
         if (mode == HM_EPI_SOFTPLUS) {
             g.ep.out1[(int64_t)m * g.ep.ld1 + n] = hm_softplus_fwd(v, g.ep.beta, g.ep.threshold);
+        } else if (mode == HM_EPI_RELU) {
+            g.ep.out1[(int64_t)m * g.ep.ld1 + n] = fmaxf(v, 0.0f);
+        } else if (mode == HM_EPI_RELUMASK) {
+            if (n < g.ep.nz) g.ep.out1[(int64_t)m * g.ep.ld1 + n] = (zv[q] > 0.0f ? v : 0.0f) + gv[q];
         } else if (mode == HM_EPI_S1MUL) {
             if (n < g.ep.nz)
                 g.ep.out1[(int64_t)m * g.ep.ld1 + n] =
@@ -495,12 +499,13 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K, co
     g.ep = hm_gemm_epilogue{};
     if (ep && ep->mode != HM_EPI_NONE) {
         HM_CHECK_ARG(!accumulate, "hm_gemm_f32_ep: an epilogue cannot be combined with accumulate");
-        HM_CHECK_ARG(ep->mode >= HM_EPI_SOFTPLUS && ep->mode <= HM_EPI_ADJOINT, "hm_gemm_f32_ep: unknown epilogue mode");
-        HM_CHECK_ARG(ep->out1 && ep->ld1 >= (ep->mode == HM_EPI_S1MUL ? ep->nz : N), "hm_gemm_f32_ep: out1");
-        if (ep->mode != HM_EPI_SOFTPLUS) {
-            const int64_t nzc = ep->mode == HM_EPI_S1MUL ? ep->nz : N;
+        HM_CHECK_ARG(ep->mode >= HM_EPI_SOFTPLUS && ep->mode <= HM_EPI_RELUMASK, "hm_gemm_f32_ep: unknown epilogue mode");
+        const bool masked = ep->mode == HM_EPI_S1MUL || ep->mode == HM_EPI_RELUMASK;   // out1 has nz columns
+        HM_CHECK_ARG(ep->out1 && ep->ld1 >= (masked ? ep->nz : N), "hm_gemm_f32_ep: out1");
+        if (ep->mode != HM_EPI_SOFTPLUS && ep->mode != HM_EPI_RELU) {
+            const int64_t nzc = masked ? ep->nz : N;
             HM_CHECK_ARG(ep->z && ep->ldz >= nzc, "hm_gemm_f32_ep: z");
-            HM_CHECK_ARG(ep->mode != HM_EPI_S1MUL || (ep->nz >= 1 && ep->nz <= N), "hm_gemm_f32_ep: nz out of range");
+            HM_CHECK_ARG(!masked || (ep->nz >= 1 && ep->nz <= N), "hm_gemm_f32_ep: nz out of range");
             HM_CHECK_ARG(!ep->g || ep->ldg >= nzc, "hm_gemm_f32_ep: g");
         }
         if (ep->mode == HM_EPI_ADJOINT) {

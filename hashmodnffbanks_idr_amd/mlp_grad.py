@@ -23,7 +23,8 @@ import math
 import torch
 
 from . import ops
-from .ops import EPI_ADJOINT, EPI_S1MUL, EPI_SOFTPLUS, _softplus_call, colsum_into, gemm, gemm_ep
+from .ops import (EPI_ADJOINT, EPI_RELU, EPI_RELUMASK, EPI_S1MUL, EPI_SOFTPLUS, _softplus_call, colsum_into, gemm,
+                  gemm_ep)
 
 _SQRT2 = math.sqrt(2.0)
 
@@ -178,3 +179,55 @@ def sdf_mlp(e, weights, biases, skip_layer, beta_sp, thr_sp, beta_rho):
     ops.require_gpu(e)
     return _SdfMlp.apply(e.contiguous(), int(skip_layer), float(beta_sp), float(thr_sp), float(beta_rho),
                          *weights, *biases)
+
+
+class _ReluMlp(torch.autograd.Function):
+    """Linear / ReLU stack of the rendering network (implicit_differentiable_renderer.py:211-221) as one
+    first-order autograd node: forward GEMMs with the ReLU on their accumulators, backward dX GEMMs with the ReLU
+    mask on theirs, weight gradients into buffers zeroed by one multi-tensor launch.  (The rendering network is
+    differentiated once - by loss.backward(); the second-order path of IDR goes through its INPUT, the normals.)"""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        L = len(params) // 2
+        Ws, bs = params[:L], params[L:]
+        acts = [x.contiguous()]
+        for l in range(L - 1):
+            acts.append(gemm_ep(acts[-1], Ws[l], bs[l], False, True, EPI_RELU, 0.0, 0.0, want_c=False)[1])
+        y = gemm(acts[-1], Ws[L - 1], bs[L - 1], False, True)
+        ctx.L = L
+        ctx.save_for_backward(*Ws, *acts)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_y):
+        L = ctx.L
+        sv = ctx.saved_tensors
+        Ws, acts = sv[:L], sv[L:]
+        need_w = ctx.needs_input_grad[1:1 + L]
+        need_b = ctx.needs_input_grad[1 + L:1 + 2 * L]
+        dW = [torch.empty_like(Ws[l]) if need_w[l] else None for l in range(L)]
+        db = [torch.empty(Ws[l].shape[0], dtype=torch.float32, device=d_y.device) if need_b[l] else None
+              for l in range(L)]
+        zero_list = [t for t in dW + db if t is not None]
+        if zero_list:
+            torch._foreach_zero_(zero_list)
+        zb = d_y.contiguous()
+        dx = None
+        for l in range(L - 1, -1, -1):
+            if need_w[l]:
+                gemm(zb, acts[l], None, True, False, out=dW[l], accumulate=True)
+            if need_b[l]:
+                colsum_into(zb, db[l])
+            if l > 0:     # h-bar_l = z-bar_l W_l, masked by relu'(z_{l-1}) = (h_l > 0)
+                zb = gemm_ep(zb, Ws[l], None, False, False, EPI_RELUMASK, 0.0, 0.0, z=acts[l], want_c=False)[1]
+            elif ctx.needs_input_grad[0]:
+                dx = gemm(zb, Ws[0], None, False, False)
+        return (dx, *dW, *db)
+
+
+def relu_mlp(x, weights, biases):
+    """Linear(+ReLU between layers) stack; differentiable once w.r.t. x, weights and biases."""
+    ops.require_gpu(x)
+    return _ReluMlp.apply(x, *weights, *biases)

@@ -253,6 +253,7 @@ class RenderingNetwork(nn.Module):
             setattr(self, "lin" + str(l), lin)
         self.relu = nn.ReLU()
         self.tanh = nn.Tanh()
+        self.use_fused_mlp = True    # Linear / ReLU stack as one autograd node (first-order); False: generic ops
         self._fold_cache = None
         for p in self.parameters():
             p.requires_grad = True
@@ -266,8 +267,12 @@ class RenderingNetwork(nn.Module):
             x = torch.cat([points, normals, feature_vectors], dim=-1)
         elif self.mode == 'no_normal':
             x = torch.cat([points, view_dirs, feature_vectors], dim=-1)
-        for l in range(self.num_layers - 1):
-            lin = getattr(self, "lin" + str(l))
+        lins = [getattr(self, "lin" + str(l)) for l in range(self.num_layers - 1)]
+        if self.use_fused_mlp and x.is_cuda and torch.is_grad_enabled():
+            # one first-order autograd node for the whole Linear / ReLU stack (mlp_grad.relu_mlp)
+            x = mlp_grad.relu_mlp(x, [_folded_weight(lin, self._fold_cache) for lin in lins], [lin.bias for lin in lins])
+            return self.tanh(x)
+        for l, lin in enumerate(lins):
             x = ops.linear(x, _folded_weight(lin, self._fold_cache), lin.bias)
             if l < self.num_layers - 2:
                 x = self.relu(x)

@@ -188,7 +188,7 @@ def gemm(a, b, bias=None, trans_a=False, trans_b=False, out=None, accumulate=Fal
     return out
 
 
-EPI_SOFTPLUS, EPI_S1MUL, EPI_ADJOINT = 1, 2, 3
+EPI_SOFTPLUS, EPI_S1MUL, EPI_ADJOINT, EPI_RELU, EPI_RELUMASK = 1, 2, 3, 4, 5
 
 
 def _rowmajor(t):
@@ -206,6 +206,7 @@ def gemm_ep(a, b, bias, trans_a, trans_b, mode, beta, thr, scale=1.0, z=None, g=
       EPI_SOFTPLUS -> (v, softplus(v))
       EPI_S1MUL    -> (v or None, v[:, :nz] * s1(z) (+ g))
       EPI_ADJOINT  -> (v * s1(z), v * g * s2(z), g * s1(z) or None)
+      EPI_RELU     -> (v or None, max(v, 0));   EPI_RELUMASK -> (v or None, where(z > 0, v, 0)[:, :nz] (+ g))
     Row-major 2-D operands with arbitrary row strides (views of wider tensors are fine); no autograd.
     out1 / out3: optional caller-owned destinations (row slices of larger buffers) for the first / third output."""
     require_gpu(a, b, bias, z, g)
@@ -219,6 +220,7 @@ def gemm_ep(a, b, bias, trans_a, trans_b, mode, beta, thr, scale=1.0, z=None, g=
     ep = _lib.GemmEpilogue()
     ep.mode, ep.scale, ep.beta, ep.threshold = mode, float(scale), float(beta), float(thr)
     c = new(N) if (want_c or mode == EPI_SOFTPLUS) else None
+    masked = mode in (EPI_S1MUL, EPI_RELUMASK)
     outs = ()
     def dest(buf, cols):
         if buf is None:
@@ -227,13 +229,13 @@ def gemm_ep(a, b, bias, trans_a, trans_b, mode, beta, thr, scale=1.0, z=None, g=
             raise ValueError("hashmod gemm_ep: bad output buffer")
         return buf
 
-    if mode == EPI_SOFTPLUS:
+    if mode in (EPI_SOFTPLUS, EPI_RELU):
         o1 = dest(out1, N)
         outs = (c, o1)
     else:
         z = _rowmajor(z)
         g = _rowmajor(g) if g is not None else None
-        ncol = (z.shape[1] if nz is None else nz) if mode == EPI_S1MUL else N
+        ncol = (z.shape[1] if nz is None else nz) if masked else N
         if z.shape[0] != M or z.shape[1] < ncol or (g is not None and (g.shape[0] != M or g.shape[1] < ncol)):
             raise ValueError("hashmod gemm_ep: epilogue operand shape")
         ep.nz = ncol
@@ -241,7 +243,7 @@ def gemm_ep(a, b, bias, trans_a, trans_b, mode, beta, thr, scale=1.0, z=None, g=
         if g is not None:
             ep.g, ep.ldg = g.data_ptr(), g.stride(0)
         o1 = dest(out1, ncol)
-        if mode == EPI_S1MUL:
+        if masked:
             outs = (c, o1)
         else:
             o2 = new(N)

@@ -201,8 +201,10 @@ HM_API int hm_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, 
  *   HM_EPI_NONE      C = v
  *   HM_EPI_SOFTPLUS  C = v;  out1 = softplus(v)                                   (forward: z and h in one pass)
  *   HM_EPI_S1MUL     C = v;  out1[:, :nz] = v[:, :nz] * s1(z) (+ g)               (gradient sweeps: u = v * s1(z))
- *   HM_EPI_ADJOINT   out1 = v * s1(z);  out2 = v * g * s2(z);  out3 = g * s1(z)    (adjoint of u = g * s1(z); out3 optional) */
-enum { HM_EPI_NONE = 0, HM_EPI_SOFTPLUS = 1, HM_EPI_S1MUL = 2, HM_EPI_ADJOINT = 3 };
+ *   HM_EPI_ADJOINT   out1 = v * s1(z);  out2 = v * g * s2(z);  out3 = g * s1(z)    (adjoint of u = g * s1(z); out3 optional)
+ *   HM_EPI_RELU      C = v;  out1 = max(v, 0)                                     (rendering MLP forward, :214-219)
+ *   HM_EPI_RELUMASK  C = v;  out1[:, :nz] = z > 0 ? v : 0                        (its backward; z = the layer's ReLU output) */
+enum { HM_EPI_NONE = 0, HM_EPI_SOFTPLUS = 1, HM_EPI_S1MUL = 2, HM_EPI_ADJOINT = 3, HM_EPI_RELU = 4, HM_EPI_RELUMASK = 5 };
 typedef struct hm_gemm_epilogue {
     int32_t mode;
     int32_t nz;               /* S1MUL: columns [0, nz) get the s1 product (z has nz columns)          */

@@ -293,3 +293,34 @@ def test_fused_forward_full_size_properties(golden, tile):
     idx = torch.randint(0, n, (512,), generator=gen)
     ref = orc(x[idx.cuda()].cpu().numpy())
     _close(s[idx.cuda()].cpu().numpy(), ref[:, 0], what="sample vs oracle")
+
+
+def test_relu_mlp_node_matches_generic_ops():
+    """mlp_grad.relu_mlp (rendering network's Linear / ReLU stack as one autograd node with ReLU GEMM epilogues)
+    against the same stack on torch ops: output and first-order gradients w.r.t. input, weights and biases."""
+    from hashmodnffbanks_idr_amd import mlp_grad
+    g = torch.Generator(device="cpu").manual_seed(11)
+    dims = [281, 512, 512, 512, 512, 3]
+    for n in (2048, 77):
+        Ws = [(torch.randn(dims[i + 1], dims[i], generator=g) / np.sqrt(dims[i])).cuda().requires_grad_(True)
+              for i in range(5)]
+        bs = [(torch.randn(dims[i + 1], generator=g) * 0.1).cuda().requires_grad_(True) for i in range(5)]
+        x = torch.randn(n, 281, generator=g).cuda().requires_grad_(True)
+        w_out = torch.randn(n, 3, generator=g).cuda()
+
+        def ref(xx):
+            h = xx
+            for l in range(5):
+                h = torch.nn.functional.linear(h.double(), Ws[l].double(), bs[l].double())
+                if l < 4:
+                    h = torch.relu(h)
+            return h
+
+        y = mlp_grad.relu_mlp(x, Ws, bs)
+        gy = torch.autograd.grad((torch.tanh(y) * w_out).sum(), [x] + Ws + bs)
+        yr = ref(x)
+        gr = torch.autograd.grad((torch.tanh(yr) * w_out.double()).sum(), [x] + Ws + bs)
+        np.testing.assert_allclose(y.detach().cpu().numpy(), yr.detach().cpu().numpy(), rtol=2e-5, atol=2e-5)
+        for a, b in zip(gy, gr):
+            scale = float(b.abs().max()) + 1e-12
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-4, atol=2e-5 * scale)
