@@ -20,7 +20,7 @@ def run():
     from hashmodnffbanks_idr_amd.model.implicit_differentiable_renderer import IDRNetwork
     from hashmodnffbanks_idr_amd.model.loss import IDRLoss
 
-    # fused SDF forward (both tile sizes) vs the C oracle
+    # fused SDF forward (every tile size) vs the C oracle
     cfg, hidden, fvs, seed = "tiny", (64,) * 8, 16, 3
     net = make_implicit(cfg, hidden, fvs, seed, 0.5, 0.5, device="cuda:0")
     L, T, b, d = P.CONFIGS[cfg]
@@ -29,7 +29,7 @@ def run():
     orc = O.SdfOracle(O.Grid(L, T, b, d), np.concatenate(levels, 0), B, prm)
     x = P.make_points(1, 1000)
     ref = orc(x)
-    for tile in (16, 64):
+    for tile in (4, 8, 16, 64):
         net.sdf_tile_points = tile
         with torch.no_grad():
             out = net(torch.from_numpy(x).to("cuda:0")).cpu().numpy()
