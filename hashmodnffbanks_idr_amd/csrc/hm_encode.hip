@@ -16,6 +16,8 @@
 // full-line coalesced stores.
 #include "hm_common.h"
 
+#include <stdlib.h>
+
 #include <math.h>
 
 namespace {
@@ -159,6 +161,123 @@ __global__ __launch_bounds__(kThreads) void encode_fwd_f2_kernel(HmLevels lv, co
 }
 
 // Generic-F fallback (F != 2): one thread per (point, level); correctness path for unusual configs.
+// ---------------------------------------------------------------------------------------------------------
+// Level-synchronous variant for big launches over tables larger than an XCD's L2.  In the tile kernel above tens
+// of thousands of short-lived workgroups are in flight at random phases, so every XCD's 4 MB L2 sees all 16 levels
+// at once (40 MB of tables at C2): a third of the fine-level corner fetches miss L2 and the kernel runs at the
+// Infinity-Cache rate.  Here ONE persistent workgroup per CU (16 waves) owns 512 points at a time and ALL CUs sweep
+// the levels in the same order, one (coarse, fine) pair at a time - identical work per tile keeps them roughly in
+// phase - so an XCD's L2 mostly holds the one fine level (4 MB at T = 2^19) everybody is reading: fabric reads per
+// launch drop from 7.84 to 5.18 GB at C2 (PMC, profiles/).  Output rows are staged in LDS (512 x 67 floats = 134 KB)
+// and leave as full-line stores, as before.
+constexpr int kTileS = 512, kThreadsS = 1024;
+
+template <int FRAC>
+__global__ __launch_bounds__(kThreadsS) void encode_fwd_f2_sweep_kernel(HmLevels lv, const float *__restrict__ x,
+                                                                        int64_t n, const float2 *__restrict__ table,
+                                                                        const float *__restrict__ Bf,
+                                                                        float *__restrict__ out, int64_t out_stride) {
+    extern __shared__ __align__(16) float smem[];
+    const int L = lv.L;
+    const bool fourier = (Bf != nullptr);
+    const int hoff = fourier ? 3 + 2 * L : 0;
+    const int E = hoff + 2 * L;
+    float *s_out = smem;               // [kTileS][E]
+    float *s_x = smem + kTileS * E;    // [kTileS][3]
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int corner = lane & 7, sub = lane >> 3;
+    const int bx = corner & 1, by = (corner >> 1) & 1, bz = (corner >> 2) & 1;
+    const int64_t n_tiles = (n + kTileS - 1) / kTileS;
+    const int half = (L + 1) / 2;
+
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t base = tile * kTileS;
+        const int cnt = (int)min((int64_t)kTileS, n - base);
+        __syncthreads();   // the previous tile's rows have left s_out
+        for (int i = tid; i < kTileS * 3; i += kThreadsS) s_x[i] = (i < cnt * 3) ? x[base * 3 + i] : 0.0f;
+        __syncthreads();
+        if (fourier) {
+            const int p = tid & (kTileS - 1);
+            const int cg = tid >> 9;  // 0..1
+            const float x0 = s_x[p * 3 + 0], x1 = s_x[p * 3 + 1], x2 = s_x[p * 3 + 2];
+            float *o = s_out + p * E;
+            if (cg == 0) {
+                o[0] = x0; o[1] = x1; o[2] = x2;
+            }
+            const float two_pi = 6.283185307179586f;
+            const float s0 = __fmul_rn(two_pi, x0), s1 = __fmul_rn(two_pi, x1), s2 = __fmul_rn(two_pi, x2);
+            for (int c = cg; c < L; c += 2) {
+                float a = __fmul_rn(s0, Bf[c]);
+                a = __fmaf_rn(s1, Bf[L + c], a);
+                a = __fmaf_rn(s2, Bf[2 * L + c], a);
+                float sn, cs;
+                sincosf(a, &sn, &cs);
+                o[3 + c] = sn;
+                o[3 + L + c] = cs;
+            }
+        }
+        // wave w owns points [32w, 32w+32) of the tile: 4 passes of 8 points x 8 corners, two levels per sweep step
+        // (gathering step lp+1 while step lp is reduced - two register sets - measured 2-7 % SLOWER)
+        for (int lp = 0; lp < half; ++lp) {
+            const int lvl[2] = {lp, lp + half};
+            float2 v[2][4];
+            float w[2][4];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int l = min(lvl[k], L - 1);
+                const int32_t res = lv.res[l];
+                const uint32_t rows = lv.rows[l], magic = lv.magic[l];
+                const float2 *tl = table + lv.row_off[l];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int p = wave * 32 + j * 8 + sub;
+                    uint32_t ux, uy, uz;
+                    float wx, wy, wz;
+                    voxel_and_weight<FRAC>(s_x[p * 3 + 0], res, bx, ux, wx);
+                    voxel_and_weight<FRAC>(s_x[p * 3 + 1], res, by, uy, wy);
+                    voxel_and_weight<FRAC>(s_x[p * 3 + 2], res, bz, uz, wz);
+                    v[k][j] = tl[hm_mod_rows(hm_hash3(ux, uy, uz), rows, magic)];
+                    w[k][j] = __fmul_rn(__fmul_rn(wx, wy), wz);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (lvl[k] >= L) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float a0 = __fmul_rn(v[k][j].x, w[k][j]);
+                    float a1 = __fmul_rn(v[k][j].y, w[k][j]);
+                    a0 = dpp_add_xor1(a0); a1 = dpp_add_xor1(a1);
+                    a0 = dpp_add_xor2(a0); a1 = dpp_add_xor2(a1);
+                    a0 = dpp_add_half_mirror(a0); a1 = dpp_add_half_mirror(a1);
+                    if (corner == 0) {
+                        float *o = s_out + (wave * 32 + j * 8 + sub) * E + hoff + 2 * lvl[k];
+                        o[0] = a0;
+                        o[1] = a1;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (out_stride == E && (reinterpret_cast<uintptr_t>(out) & 15u) == 0) {
+            float *dst = out + base * E;   // 16-B aligned: kTileS*E*4 is a multiple of 16
+            const int total = cnt * E;
+            const int nvec = total >> 2;
+            const float4 *s4 = reinterpret_cast<const float4 *>(s_out);
+            float4 *d4 = reinterpret_cast<float4 *>(dst);
+            for (int i = tid; i < nvec; i += kThreadsS) d4[i] = s4[i];
+            for (int i = (nvec << 2) + tid; i < total; i += kThreadsS) dst[i] = s_out[i];
+        } else {
+            for (int i = tid; i < cnt * E; i += kThreadsS) {
+                const int p = i / E, c = i - p * E;
+                out[(base + p) * out_stride + c] = s_out[i];
+            }
+        }
+    }
+}
+
+
 template <int FRAC>
 __global__ __launch_bounds__(kThreads) void encode_fwd_generic_kernel(HmLevels lv, const float *__restrict__ x,
                                                                       int64_t n, const float *__restrict__ table,
@@ -283,7 +402,32 @@ int hm_encode_fwd(const hm_grid_desc *desc, const float *x, int64_t n, const flo
     HM_CHECK_ARG(out_stride >= width, "hm_encode_fwd: out_stride < row width");
     if (n == 0) return HM_OK;
     HM_CHECK_ARG(x && table && out, "hm_encode_fwd: NULL pointer");
-    if (lv.F == 2) {
+    static const int sweep_cfg = [] { const char *e = getenv("HM_ENCODE_SWEEP"); return e ? atoi(e) : 1; }();
+    const size_t lds_sweep = sizeof(float) * (size_t)(kTileS * width + kTileS * 3);
+    const bool table_exceeds_l2 = desc->total_rows * (uint64_t)lv.F * 4u > (8u << 20);   // (C1's 0.9 MiB: tile kernel)
+    if (lv.F == 2 && sweep_cfg != 0 && table_exceeds_l2 && n >= (int64_t)kTileS * 256 && lds_sweep <= 160 * 1024) {
+        // big launches over big tables: level-synchronous persistent kernel (one workgroup per CU)
+        static thread_local bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_fwd_f2_sweep_kernel<HM_FRAC_REFERENCE>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_fwd_f2_sweep_kernel<HM_FRAC_TRILINEAR>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return hm_fail(HM_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+            attr_done = true;
+        }
+        const int64_t tiles = (n + kTileS - 1) / kTileS;
+        const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
+        if (frac_mode == HM_FRAC_REFERENCE)
+            hipLaunchKernelGGL(encode_fwd_f2_sweep_kernel<HM_FRAC_REFERENCE>, dim3(grid), dim3(kThreadsS), lds_sweep,
+                               as_stream(stream), lv, x, n, reinterpret_cast<const float2 *>(table), B_fourier, out,
+                               out_stride);
+        else
+            hipLaunchKernelGGL(encode_fwd_f2_sweep_kernel<HM_FRAC_TRILINEAR>, dim3(grid), dim3(kThreadsS), lds_sweep,
+                               as_stream(stream), lv, x, n, reinterpret_cast<const float2 *>(table), B_fourier, out,
+                               out_stride);
+    } else if (lv.F == 2) {
         const int64_t tiles = (n + kTile - 1) / kTile;
         HM_CHECK_ARG(tiles <= 0x7fffffffLL, "hm_encode_fwd: n too large for one launch");
         const size_t lds = sizeof(float) * (size_t)(kTile * width + kTile * 3);
