@@ -165,12 +165,13 @@ __global__ __launch_bounds__(kThreads) void encode_fwd_f2_kernel(HmLevels lv, co
 // Level-synchronous variant for big launches over tables larger than an XCD's L2.  In the tile kernel above tens
 // of thousands of short-lived workgroups are in flight at random phases, so every XCD's 4 MB L2 sees all 16 levels
 // at once (40 MB of tables at C2): a third of the fine-level corner fetches miss L2 and the kernel runs at the
-// Infinity-Cache rate.  Here ONE persistent workgroup per CU (16 waves) owns 512 points at a time and ALL CUs sweep
+// Infinity-Cache rate.  Here TWO persistent workgroups per CU (8 waves each) own 256 points at a time and ALL of them sweep
 // the levels in the same order, one (coarse, fine) pair at a time - identical work per tile keeps them roughly in
 // phase - so an XCD's L2 mostly holds the one fine level (4 MB at T = 2^19) everybody is reading: fabric reads per
-// launch drop from 7.84 to 5.18 GB at C2 (PMC, profiles/).  Output rows are staged in LDS (512 x 67 floats = 134 KB)
+// launch drop from 7.84 to 5.18 GB at C2 (PMC, profiles/).  Output rows are staged in LDS (256 x 67 floats = 67 KB per workgroup)
 // and leave as full-line stores, as before.
-constexpr int kTileS = 512, kThreadsS = 1024;
+constexpr int kTileS = 256, kThreadsS = 512;   // two workgroups per CU: one gathers while the other stores
+                                               // (one of 512 points: 4.53 TB/s, two of 256: 4.65, four of 128: 4.45)   // two workgroups per CU: one gathers while the other stores
 
 template <int FRAC>
 __global__ __launch_bounds__(kThreadsS) void encode_fwd_f2_sweep_kernel(HmLevels lv, const float *__restrict__ x,
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(kThreadsS) void encode_fwd_f2_sweep_kernel(HmLevels
         __syncthreads();
         if (fourier) {
             const int p = tid & (kTileS - 1);
-            const int cg = tid >> 9;  // 0..1
+            const int cg = tid / kTileS;  // 0..1
             const float x0 = s_x[p * 3 + 0], x1 = s_x[p * 3 + 1], x2 = s_x[p * 3 + 2];
             float *o = s_out + p * E;
             if (cg == 0) {
@@ -405,8 +406,8 @@ int hm_encode_fwd(const hm_grid_desc *desc, const float *x, int64_t n, const flo
     static const int sweep_cfg = [] { const char *e = getenv("HM_ENCODE_SWEEP"); return e ? atoi(e) : 1; }();
     const size_t lds_sweep = sizeof(float) * (size_t)(kTileS * width + kTileS * 3);
     const bool table_exceeds_l2 = desc->total_rows * (uint64_t)lv.F * 4u > (8u << 20);   // (C1's 0.9 MiB: tile kernel)
-    if (lv.F == 2 && sweep_cfg != 0 && table_exceeds_l2 && n >= (int64_t)kTileS * 256 && lds_sweep <= 160 * 1024) {
-        // big launches over big tables: level-synchronous persistent kernel (one workgroup per CU)
+    if (lv.F == 2 && sweep_cfg != 0 && table_exceeds_l2 && n >= (int64_t)131072 && lds_sweep <= 160 * 1024) {
+        // big launches over big tables: level-synchronous persistent kernel (two workgroups per CU)
         static thread_local bool attr_done = false;
         if (!attr_done) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_fwd_f2_sweep_kernel<HM_FRAC_REFERENCE>),
@@ -418,7 +419,7 @@ int hm_encode_fwd(const hm_grid_desc *desc, const float *x, int64_t n, const flo
             attr_done = true;
         }
         const int64_t tiles = (n + kTileS - 1) / kTileS;
-        const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
+        const unsigned grid = (unsigned)(tiles < 512 ? tiles : 512);
         if (frac_mode == HM_FRAC_REFERENCE)
             hipLaunchKernelGGL(encode_fwd_f2_sweep_kernel<HM_FRAC_REFERENCE>, dim3(grid), dim3(kThreadsS), lds_sweep,
                                as_stream(stream), lv, x, n, reinterpret_cast<const float2 *>(table), B_fourier, out,
