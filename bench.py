@@ -9,11 +9,22 @@ A "step" = one training iteration of the hot path on one batch of synthetic unif
 IDRNetwork.forward (sphere tracing with the fused SDF kernel, grad-enabled SDF / rendering MLPs,
 gradient() with create_graph) + IDRLoss + backward + [gradient all-reduce] + clip_grad_norm_ + Adam.
 Workload = BASELINE.json configs[1]: MultiResHash L=16 T=2^19 F=2, 2048 rays PER GPU (weak
-scaling), fp32, geometric-init weights seed 0, object_mask all true, rgb_gt = 0.
+scaling), fp32, geometric-init weights seed 0, object_mask all true, rgb_gt = 0
+(`--gpus 8`: configs[3], T=2^22, 16 384 rays over the 8 GPUs).
+
+Two legs are timed, each over exactly K steps:
+  value / ms_per_step   the section-8(d) workload: the weights STAY at the geometric initialisation (the whole
+                        iteration runs, optimizer included, with lr = 0), so every timed step traces the same
+                        surface: ~123 SDF evaluations per ray;
+  train_leg             the same iteration with lr = 1e-4 (Adam moves the surface while the clock runs, the per-ray
+                        work drifts with the step count - reported, never the headline).
+config.sdf_evals_per_step holds the measured SDF evaluations of the timed steps (mean / min / max).
 
 Extra objects on the same line:
   roofline      hash-gather kernel (BASELINE metric "hash-gather HBM GB/s"): algorithmic bytes
                 (1304 B/point at L=16,F=2) x 2^22 points / HIP-event time per launch
+  roofline_c4   the same kernel over the configs[3] table (T=2^22: 223.5 MiB, larger than the 32 MiB of L2)
+  roofline_bwd  table-gradient scatter: 2188 B/point
   roofline_mlp  fused SDF forward kernel (the kernel that dominates the step): 3.93 MFLOP/point
                 against the 157.3 TFLOP/s fp32 MFMA peak
   cpu_baseline  oracle/torch_ref.py (a port: the reference's op sequence on torch-CPU) timed on
@@ -39,7 +50,7 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s ach
 MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
 SDF_MAC_PER_POINT = 1966592  # SURVEY.md 8a row A9 (independent of the embedding width)
 RAYS_PER_GPU = 2048
-CFG = "C2"
+CFG = "C2"          # BASELINE.json configs[1]; `--gpus 8` defaults to configs[3] ("C4", T=2^22)
 
 
 class Conf(dict):
@@ -130,12 +141,16 @@ def gather_roofline(emb, log2_n=22, iters=10, warmup=3):
     avg_ms = float(ms.mean())
     achieved = n * bpp / (avg_ms * 1e-3) / 1e9
     traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r01_gather_pmc.json")
-    if os.path.exists(pmc) and log2_n == 22 and emb.n_levels == 16 and emb.table.shape[0] == 5217937:
-        # PMC counters cannot be read from inside this process: the number comes from the separate
-        # rocprofv3 --pmc passes of `bench.py --only gather` recorded under profiles/ (same kernel, same launch)
-        rec = json.load(open(pmc))
-        traffic, traffic_src = round(rec["traffic_bytes_per_launch_corrected"]), "profiles/r01_gather_pmc.json"
+    # PMC counters cannot be read from inside this process: the number comes from the separate
+    # rocprofv3 --pmc passes of `bench.py --only gather [--cfg C4]` recorded under profiles/ (same kernel, same launch)
+    tag = {5217937: "C2", 29295887: "C4"}.get(int(emb.table.shape[0]))
+    for rnd in ("r02", "r01"):
+        name = f"{rnd}_gather_pmc.json" if tag == "C2" else f"{rnd}_gather_{tag}_pmc.json"
+        pmc = os.path.join(ROOT, "profiles", name)
+        if tag and os.path.exists(pmc) and log2_n == 22 and emb.n_levels == 16:
+            rec = json.load(open(pmc))
+            traffic, traffic_src = round(rec["traffic_bytes_per_launch_corrected"]), "profiles/" + name
+            break
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": n * bpp,
@@ -143,7 +158,8 @@ def gather_roofline(emb, log2_n=22, iters=10, warmup=3):
             else "encode_fwd_f2_kernel",
             "units_per_launch": n, "bytes_per_unit": bpp, "avg_launch_ms": round(avg_ms, 4),
             "min_launch_ms": round(float(ms.min()), 4),
-            "note": f"table {emb.table.numel() * 4 / 2**20:.1f} MiB is Infinity-Cache resident (<256 MiB)"}
+            "note": f"table {emb.table.numel() * 4 / 2**20:.1f} MiB is Infinity-Cache resident (<256 MiB)"
+                    + ("" if emb.table.numel() * 4 > (32 << 20) else " and L2 resident (32 MiB aggregate)")}
 
 
 def gather_bwd_roofline(emb, log2_n=22, iters=10, warmup=3):
@@ -250,6 +266,8 @@ def cpu_baseline(model, n_rays=256, reps=2):
     except OSError:
         pass
     return {"value": round(n_rays / dt, 2), "unit": "rays/s", "cores": best_threads, "kind": "port",
+            "config": f"{n_rays}-ray sample of the {RAYS_PER_GPU}-ray batch (same rays seed, same parameters as the GPU "
+                      "run's headline leg); single_thread: 32-ray sample",
             "sample": f"{n_rays} of {RAYS_PER_GPU} rays, {reps} fwd+loss+bwd steps of oracle/torch_ref.py (torch-CPU, "
                       f"best of the thread sweep: {best_threads} threads), {dt:.2f} s/step",
             "threads_sweep": [{"threads": nt, "rays_per_s": round(n_rays / t, 2)} for nt, t in sweep],
@@ -259,64 +277,23 @@ def cpu_baseline(model, n_rays=256, reps=2):
                                         f"{dt1:.2f} s/step"}}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--rays", type=int, default=RAYS_PER_GPU, help="rays per GPU")
-    ap.add_argument("--no-extras", action="store_true", help="skip roofline / cpu_baseline sections")
-    ap.add_argument("--no-graph", action="store_true",
-                    help="eager reference-structured step (dynamic shapes) instead of the HIP-graph captured step")
-    ap.add_argument("--torch-adam", action="store_true",
-                    help="torch.nn.utils.clip_grad_norm_ + torch.optim.Adam instead of the fused training.optim.ClipAdam")
-    ap.add_argument("--gather-log2n", type=int, default=22)
-    ap.add_argument("--only", choices=["gather", "gather_bwd", "mlp"], default=None,
-                    help="profiling helper: run just one kernel section on cuda:0 and print its object")
-    ap.add_argument("--cfg", default=CFG, help="hash-grid config for --only sections (tests/golden/params.py)")
-    args = ap.parse_args()
-
-    if args.only:
-        torch.manual_seed(0)
-        dev = torch.device("cuda", 0)
-        from hashmodnffbanks_idr_amd.model.implicit_differentiable_renderer import IDRNetwork
-        model = IDRNetwork(idr_conf(args.cfg)).to(dev)
-        emb = model.implicit_network.embed_model.embedder_obj
-        if args.only == "gather":
-            print(json.dumps(gather_roofline(emb, args.gather_log2n)))
-        elif args.only == "gather_bwd":
-            print(json.dumps(gather_bwd_roofline(emb, args.gather_log2n)))
-        else:
-            print(json.dumps(mlp_roofline(model.implicit_network)))
-        return
-
-    from hashmodnffbanks_idr_amd import parallel
+def _build(cfg, device, lr):
     from hashmodnffbanks_idr_amd.model.implicit_differentiable_renderer import IDRNetwork
-    from hashmodnffbanks_idr_amd.model.loss import IDRLoss
-
-    rank, world, local_rank = parallel.init_distributed()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    n_dev = torch.cuda.device_count()
-    device = torch.device("cuda", local_rank % max(n_dev, 1))  # (rehearsal: several gloo ranks may share one GPU)
-    torch.cuda.set_device(device)
-
-    torch.manual_seed(0)  # identical replicas on every rank
-    model = IDRNetwork(idr_conf(CFG)).to(device)
+    from hashmodnffbanks_idr_amd.training.optim import ClipAdam
+    torch.manual_seed(0)  # identical replicas on every rank: geometric init, seed 0
+    model = IDRNetwork(idr_conf(cfg)).to(device)
     model.train()
     if os.environ.get("HM_FUSED_MLP_GRAD", "1") == "0":   # debugging switch: generic autograd route for gradient()
         model.implicit_network.use_fused_mlp_grad = False
-    loss_fn = IDRLoss(eikonal_weight=0.1, mask_weight=100.0, alpha=50.0)
-    # dense Adam over ALL parameters incl. the hash table (reference: idr_train.py:127-128)
-    if args.torch_adam:
-        opt = torch.optim.Adam(model.parameters(), lr=1.0e-4, capturable=not args.no_graph)
-    else:   # same update, clip_grad_norm_(1.0) + Adam in three launches (csrc/hm_optim.hip)
-        from hashmodnffbanks_idr_amd.training.optim import ClipAdam
-        opt = ClipAdam(model.parameters(), lr=1.0e-4, max_norm=1.0)
-    reducer = parallel.GradAllReducer(model.parameters()) if world > 1 else None
-    inp, gt = synthetic_batch(1234 + rank, args.rays, device)
-    torch.manual_seed(100 + rank)  # per-rank eikonal points / step fractions
+    return model
+
+
+def _run_leg(args, model, opt, loss_fn, reducer, inp, gt, world, device, rank):
+    """W untimed warm-up steps, then EXACTLY K timed steps between barrier + synchronize; max over ranks."""
+    from hashmodnffbanks_idr_amd import parallel
     if args.no_graph:
+        stepper = None
+
         def run_step():
             return parallel.train_step(model, loss_fn, opt, inp, gt, reducer)
     else:
@@ -335,39 +312,137 @@ def main():
 
     for _ in range(args.warmup):
         run_step()
+    # tracer statistics of every timed step, kept on the device (no host read inside the timed region)
+    hist = torch.zeros((args.steps, 16), dtype=torch.int32, device=device)
+    rt = model.ray_tracer
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         _, lo = run_step()
+        if rt._stats_dev is not None:
+            hist[i].copy_(rt._stats_dev, non_blocking=True)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+    h = hist.cpu().numpy().astype(np.int64)
+    ev = h[:, 6]
+    stats = {"rays": args.rays, "mean": round(float(ev.mean()), 1), "min": int(ev.min()), "max": int(ev.max()),
+             "per_ray_mean": round(float(ev.mean()) / args.rays, 2), "sampler_rays_mean": round(float(h[:, 0].mean()), 1),
+             "mask_loss_rays_mean": round(float(h[:, 3].mean()), 1), "unfinished_max": int(h[:, 7].max()),
+             "nonfinite_sdf_max": int(h[:, 8].max())}
+    mode = ("eager (reference-structured, dynamic shapes)" if args.no_graph
+            else ("HIP-graph captured static-shape step" if stepper.g_fb is not None
+                  else "eager static-shape step (graph capture unavailable)"))
+    return dt, stats, float(lo["loss"].item()), mode
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rays", type=int, default=RAYS_PER_GPU, help="rays per GPU")
+    ap.add_argument("--no-extras", action="store_true", help="skip roofline / cpu_baseline sections")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="eager reference-structured step (dynamic shapes) instead of the HIP-graph captured step")
+    ap.add_argument("--torch-adam", action="store_true",
+                    help="torch.nn.utils.clip_grad_norm_ + torch.optim.Adam instead of the fused training.optim.ClipAdam")
+    ap.add_argument("--legs", choices=["both", "fixed", "train"], default="both",
+                    help="fixed = section-8(d) workload (weights stay at geometric init; the headline); train = lr 1e-4")
+    ap.add_argument("--gather-log2n", type=int, default=22)
+    ap.add_argument("--only", choices=["gather", "gather_bwd", "mlp"], default=None,
+                    help="profiling helper: run just one kernel section on cuda:0 and print its object")
+    ap.add_argument("--cfg", default=None,
+                    help="hash-grid config (tests/golden/params.py): default C2 = BASELINE configs[1]; C4 = configs[3] "
+                         "is the default for --gpus 8")
+    args = ap.parse_args()
+    cfg = args.cfg or os.environ.get("HM_BENCH_CFG") or ("C4" if args.gpus == 8 else CFG)
+
+    if args.only:
+        dev = torch.device("cuda", 0)
+        model = _build(cfg, dev, 0.0)
+        emb = model.implicit_network.embed_model.embedder_obj
+        if args.only == "gather":
+            print(json.dumps(gather_roofline(emb, args.gather_log2n)))
+        elif args.only == "gather_bwd":
+            print(json.dumps(gather_bwd_roofline(emb, args.gather_log2n)))
+        else:
+            print(json.dumps(mlp_roofline(model.implicit_network)))
+        return
+
+    from hashmodnffbanks_idr_amd import parallel
+    from hashmodnffbanks_idr_amd.model.loss import IDRLoss
+
+    rank, world, local_rank = parallel.init_distributed()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    n_dev = torch.cuda.device_count()
+    device = torch.device("cuda", local_rank % max(n_dev, 1))  # (rehearsal: several gloo ranks may share one GPU)
+    torch.cuda.set_device(device)
+    loss_fn = IDRLoss(eikonal_weight=0.1, mask_weight=100.0, alpha=50.0)
+    inp, gt = synthetic_batch(1234 + rank, args.rays, device)
+    L, T = P.CONFIGS[cfg][0], P.CONFIGS[cfg][1]
+
+    def make_opt(model, lr):
+        # dense Adam over ALL parameters incl. the hash table (reference: idr_train.py:127-128)
+        if args.torch_adam:
+            return torch.optim.Adam(model.parameters(), lr=lr, capturable=not args.no_graph)
+        from hashmodnffbanks_idr_amd.training.optim import ClipAdam   # clip_grad_norm_(1.0) + Adam in three launches
+        return ClipAdam(model.parameters(), lr=lr, max_norm=1.0)
+
+    legs = {}
+    model = None
+    for leg, lr in (("fixed", 0.0), ("train", 1.0e-4)):
+        if args.legs not in ("both", leg):
+            continue
+        model = _build(cfg, device, lr)
+        reducer = parallel.GradAllReducer(model.parameters()) if world > 1 else None
+        torch.manual_seed(100 + rank)  # per-rank eikonal points / step fractions
+        dt, stats, final_loss, mode = _run_leg(args, model, make_opt(model, lr), loss_fn, reducer, inp, gt, world,
+                                               device, rank)
+        legs[leg] = {"value": round(args.rays * world * args.steps / dt, 1), "unit": "rays/s",
+                     "ms_per_step": round(dt / args.steps * 1e3, 3), "lr": lr, "sdf_evals_per_step": stats,
+                     "final_loss": round(final_loss, 6), "step": mode}
+        if leg == "fixed":
+            head_model = model
+    if "fixed" not in legs:
+        head_model = model
 
     if rank == 0:
-        total_rays = args.rays * world * args.steps
+        head = legs.get("fixed") or legs["train"]
         line = {
-            "metric": "rays/sec fwd+bwd (hash+SDF MLP)", "value": round(total_rays / dt, 1), "unit": "rays/s",
+            "metric": "rays/sec fwd+bwd (hash+SDF MLP)", "value": head["value"], "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "DTU-shaped synthetic uniform-sphere rays, MultiResHash L=16 T=2^19 F=2 "
-                                   "(BASELINE.json configs[1]), full IDR training step",
-                       "rays_per_gpu": args.rays, "global_rays": args.rays * world,
+            "config": {"workload": f"DTU-shaped synthetic uniform-sphere rays, MultiResHash L={L} T=2^{T} F=2 "
+                                   f"(BASELINE.json configs[{3 if cfg == 'C4' else 1}]), full IDR training step "
+                                   "(forward + IDRLoss + backward + clip + Adam)"
+                                   + (", weights held at the geometric initialisation (lr = 0): the SURVEY.md 8(d) workload"
+                                      if "fixed" in legs else ", lr 1e-4 (surface moves during the timed region)"),
+                       "grid_config": cfg, "rays_per_gpu": args.rays, "global_rays": args.rays * world,
                        "parallelism": f"ray-sharded dp{world}" if world > 1 else "single GPU",
-                       "step": "eager (reference-structured, dynamic shapes)" if args.no_graph
-                       else ("HIP-graph captured static-shape step" if stepper.g_fb is not None
-                             else "eager static-shape step (graph capture unavailable)"),
-                       "sdf_evals_per_ray_tracing": model.ray_tracer.last_stats},
-            "final_loss": round(float(lo["loss"].item()), 6),
+                       "step": head["step"], "sdf_evals_per_step": head["sdf_evals_per_step"]},
+            "final_loss": head["final_loss"],
         }
+        if "fixed" in legs and "train" in legs:
+            line["train_leg"] = legs["train"]
         if not args.no_extras:
-            emb = model.implicit_network.embed_model.embedder_obj
+            emb = head_model.implicit_network.embed_model.embedder_obj
             line["roofline"] = gather_roofline(emb, args.gather_log2n)
-            line["roofline_mlp"] = mlp_roofline(model.implicit_network)
-            line["cpu_baseline"] = cpu_baseline(model)
+            line["roofline_bwd"] = gather_bwd_roofline(emb, args.gather_log2n, iters=5, warmup=2)
+            line["roofline_mlp"] = mlp_roofline(head_model.implicit_network)
+            if cfg != "C4":
+                from hashmodnffbanks_idr_amd.model.embeddings.hashGridEmbedding import MultiResHashGridMLP
+                Lc, Tc, bc, dc = P.CONFIGS["C4"]
+                torch.manual_seed(0)
+                emb4 = MultiResHashGridMLP(True, 3, Lc, 2, Tc, bc, dc).to(device)
+                line["roofline_c4"] = gather_roofline(emb4, args.gather_log2n)
+                del emb4
+            line["cpu_baseline"] = cpu_baseline(head_model)
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -37,6 +37,7 @@ SIGNATURES = {
     "hm_sdf_head": (_int, [_int, _p, _i64, _i64, C.c_float, _p, _p, _p, _p, _p, _p]),
     "hm_colsum": (_int, [_p, _i64, _i64, _i64, _p, _p]),
     "hm_colsum_acc": (_int, [_p, _i64, _i64, _i64, _p, _p]),
+    "hm_copy2d_f32": (_int, [_p, _i64, _p, _i64, _i64, _i64, _p]),
     "hm_idr_loss": (_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, C.c_float, C.c_float, C.c_float, _p, _p, _p, _p, _p]),
     "hm_adam_step": (_int, [_p, _int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _p, _p]),
     "hm_gemm_f32_ep": (_int, [_int, _int, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _p]),
@@ -74,6 +75,20 @@ class MlpDesc(C.Structure):
 
 class HashmodError(RuntimeError):
     pass
+
+
+# Parameters written through raw pointers (hm_adam_step, graph replays) do not bump torch's tensor._version, so
+# every cache derived from parameter VALUES (ImplicitNetwork.packed_weights) also keys on this counter; every
+# writer that bypasses ATen calls bump_param_epoch().
+_param_epoch = [0]
+
+
+def param_epoch():
+    return _param_epoch[0]
+
+
+def bump_param_epoch():
+    _param_epoch[0] += 1
 
 
 def lib():

@@ -197,6 +197,38 @@ static int colsum_impl(const float *x, int64_t M, int64_t N, int64_t ld, float *
     return HM_OK;
 }
 
+// 2-D copy as a KERNEL (hipMemcpy2DAsync / hipMemcpyAsync would become MEMCPY nodes of a captured graph)
+__global__ __launch_bounds__(256) void copy2d_kernel(float *__restrict__ dst, int64_t ldd,
+                                                     const float *__restrict__ src, int64_t lds_, int64_t rows,
+                                                     int64_t cols, int vec4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (vec4) {
+        const int64_t c4 = cols >> 2;
+        if (i >= rows * c4) return;
+        const int64_t r = i / c4, c = (i - r * c4) << 2;
+        *reinterpret_cast<float4 *>(dst + r * ldd + c) = *reinterpret_cast<const float4 *>(src + r * lds_ + c);
+    } else {
+        if (i >= rows * cols) return;
+        const int64_t r = i / cols, c = i - r * cols;
+        dst[r * ldd + c] = src[r * lds_ + c];
+    }
+}
+
+int hm_copy2d_f32(float *dst, int64_t ld_dst, const float *src, int64_t ld_src, int64_t rows, int64_t cols,
+                  void *stream) {
+    HM_CHECK_ARG(rows >= 0 && cols >= 0 && ld_dst >= cols && ld_src >= cols, "hm_copy2d_f32: bad shape");
+    if (rows == 0 || cols == 0) return HM_OK;
+    HM_CHECK_ARG(dst && src, "hm_copy2d_f32: NULL pointer");
+    const bool v4 = (cols % 4 == 0) && (ld_dst % 4 == 0) && (ld_src % 4 == 0) &&
+                    ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) % 16 == 0);
+    const int64_t work = v4 ? rows * (cols / 4) : rows * cols;
+    HM_CHECK_ARG((work + 255) / 256 < (1ll << 31), "hm_copy2d_f32: too large");
+    hipLaunchKernelGGL(copy2d_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, as_stream(stream), dst, ld_dst,
+                       src, ld_src, rows, cols, v4 ? 1 : 0);
+    HM_CHECK_LAUNCH("hm_copy2d_f32");
+    return HM_OK;
+}
+
 int hm_colsum(const float *x, int64_t M, int64_t N, int64_t ld, float *out, void *stream) {
     return colsum_impl(x, M, N, ld, out, true, stream);
 }

@@ -29,6 +29,8 @@ enum : int32_t {  // counters (device int32 array)
     C_ANY_LIVE = 69,     // some ray was still marching after the first evaluation (=> >= 1 global iteration)
     C_EVALS = 70,        // total SDF point evaluations (statistics)
     C_UNFINISHED = 71,   // rays whose state machine had not finished after the last march round
+    C_NONFINITE = 72,    // SDF values consumed by the search that were NaN / Inf (must be 0: a NaN fails every
+                         // `sdf > threshold` test, so the ray would silently count as converged where it stands)
     C_COUNT = 80
 };
 
@@ -111,6 +113,7 @@ __global__ __launch_bounds__(kTB) void trace_advance_kernel(TraceArgs a, int rou
     const int32_t ss = w.slot_s[i], se = w.slot_e[i];
     if (ss >= 0) nxt_s = w.vals[ss];
     if (se >= 0) nxt_e = w.vals[se];
+    if ((ss >= 0 && !isfinite(nxt_s)) || (se >= 0 && !isfinite(nxt_e))) atomicAdd(w.cnt + C_NONFINITE, 1);
     int32_t *cursor = w.cnt + C_ROUND0 + round;
     int32_t new_ss = -1, new_se = -1;
     const bool first = (st == ST_WAIT_FIRST);
@@ -224,15 +227,17 @@ __global__ __launch_bounds__(kTB) void sampler_reduce_kernel(TraceArgs a) {
     const int64_t i = w.list_samp[m];
     const int n = a.n_steps;
     const float *v = w.vals + m * n;
-    int first = 0, amin = 0;
+    int first = 0, amin = 0, bad = 0;
     float best_tmp = 0.0f, best_v = 0.0f;
     for (int s = 0; s < n; ++s) {
         const float x = v[s];
+        bad += !isfinite(x);
         const float sg = (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f);
         const float tmp = sg * (float)(n - s);  // sign(sdf) * arange(n, 0, -1)
         if (s == 0 || tmp < best_tmp) { best_tmp = tmp; first = s; }
         if (s == 0 || x < best_v) { best_v = x; amin = s; }
     }
+    if (bad) atomicAdd(w.cnt + C_NONFINITE, bad);
     const float lo = w.t_s[i], hi = w.t_e[i];
     auto t_at = [&](int s) { return __fadd_rn(lo, __fmul_rn(a.fracs[s], __fsub_rn(hi, lo))); };
     const float v_first = v[first];
@@ -277,6 +282,7 @@ __global__ __launch_bounds__(kTB) void secant_advance_kernel(TraceArgs a, int la
     const TraceWs &w = a.w;
     if (q >= w.cnt[C_NSEC]) return;
     const float v = w.vals[q];
+    if (!isfinite(v)) atomicAdd(w.cnt + C_NONFINITE, 1);
     float z = w.z[q], z_lo = w.z_lo[q], z_hi = w.z_hi[q], v_lo = w.v_lo[q], v_hi = w.v_hi[q];
     if (v > 0.0f) { z_lo = z; v_lo = v; }
     if (v < 0.0f) { z_hi = z; v_hi = v; }
@@ -328,10 +334,13 @@ __global__ __launch_bounds__(kTB) void closest_reduce_kernel(TraceArgs a) {
     const int64_t i = w.list_sel[m];
     const int n = a.n_steps;
     const float *v = w.vals + m * n;
-    int amin = 0;
+    int amin = 0, bad = !isfinite(v[0]);
     float best = v[0];
-    for (int s = 1; s < n; ++s)
+    for (int s = 1; s < n; ++s) {
+        bad += !isfinite(v[s]);
         if (v[s] < best) { best = v[s]; amin = s; }
+    }
+    if (bad) atomicAdd(w.cnt + C_NONFINITE, bad);
     const float lo = w.t_min[i], hi = w.t_max[i];
     const float t = __fadd_rn(__fmul_rn(a.steps_u[amin], __fsub_rn(hi, lo)), lo);
     float px, py, pz;
@@ -478,7 +487,7 @@ int hm_trace_forward(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const flo
     hipLaunchKernelGGL(count_evals_kernel, dim3(1), dim3(64), 0, st, a.w.cnt, rounds + 1, cfg->n_secant_steps);
     if (stats_out) {
         hipLaunchKernelGGL(hm_copy_u32_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<uint32_t *>(stats_out),
-                           reinterpret_cast<const uint32_t *>(a.w.cnt + C_NSAMP), 8);
+                           reinterpret_cast<const uint32_t *>(a.w.cnt + C_NSAMP), 16);
     }
     HM_CHECK_LAUNCH("hm_trace_forward");
     return HM_OK;

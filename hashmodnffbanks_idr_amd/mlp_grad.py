@@ -48,7 +48,7 @@ class _SdfMlp(torch.autograd.Function):
         h = None
         for l in range(L):
             if l == 0:
-                a = e if stack[0] is None else lower(0).copy_(e)
+                a = e if stack[0] is None else ops.dcopy_(lower(0), e)   # (kernel copy: no MEMCPY graph node)
             elif l == skip_layer:
                 a = torch.cat([h, e], 1, out=lower(l)).div_(_SQRT2) if stack[l] is not None \
                     else torch.cat([h, e], 1) / _SQRT2
@@ -127,7 +127,7 @@ class _SdfMlp(torch.autograd.Function):
                     vb = (torch.cat([vb_h, d_ge], 1, out=stack[l][:N]) if stacked else torch.cat([vb_h, d_ge], 1))
                     vb = vb.div_(_SQRT2)
                 elif stacked and vb_h.data_ptr() != stack[l].data_ptr():
-                    vb = stack[l][:N].copy_(vb_h)                # (layer 0, or after an unstacked layer)
+                    vb = ops.dcopy_(stack[l][:N], vb_h)          # (layer 0, or after an unstacked layer)
                 else:
                     vb = vb_h
                 if l < L - 1:

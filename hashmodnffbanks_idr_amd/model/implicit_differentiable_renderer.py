@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import mlp_grad, ops
+from .. import _lib, mlp_grad, ops
 from ..utils import rend_util
 from .custom_embedder_decoder import Custom_Embedding_Network
 from .density_net import LaplaceDensity
@@ -129,7 +129,9 @@ class ImplicitNetwork(nn.Module):
     def packed_weights(self):
         """Fold weight-norm and pack the MFMA operand images; cached until a parameter changes."""
         ps = self._lin_params() + [self.dencity_net.beta]
-        key = tuple((p.data_ptr(), p._version) for p in ps)
+        # _version does not see writes through raw pointers (training.optim.ClipAdam, graph replays): those bump
+        # _lib.param_epoch(), which is part of the key
+        key = (_lib.param_epoch(),) + tuple((p.data_ptr(), p._version) for p in ps)
         if self._packed is None or key != self._packed_key or self._force_repack:
             self._force_repack = False
             with torch.no_grad():

@@ -47,7 +47,7 @@ class RayTracing(nn.Module):
             v = self._stats_dev.tolist()
             # (the device tensor is kept: inside a captured graph it is refreshed by every replay)
             self._stats = {"rays": self._stats.get("rays"), "sampler_rays": v[0], "secant_rays": v[2],
-                           "mask_loss_rays": v[3], "sdf_evals": v[6], "unfinished": v[7]}
+                           "mask_loss_rays": v[3], "sdf_evals": v[6], "unfinished": v[7], "nonfinite": v[8]}
         return self._stats
 
     def _fused_network(self, sdf, ray_directions):
@@ -80,7 +80,7 @@ class RayTracing(nn.Module):
                     # same generator call as the reference (:277); it is made even when no ray ends up needing it
                     steps_u = torch.empty(self.n_steps).uniform_(0.0, 1.0).to(dev)
             emb = net._hash_embedder()
-            stats = torch.zeros(8, dtype=torch.int32, device=dev)
+            stats = torch.zeros(16, dtype=torch.int32, device=dev)
             pts, mask, dists = ops.trace_forward(
                 emb.desc, net.packed_weights(), emb.table.detach(), emb.freq_encoding.B,
                 ops.FRAC_MODES[emb.frac_mode], net.sdf_tile_points, cfg, cam_loc.detach().contiguous().float(),

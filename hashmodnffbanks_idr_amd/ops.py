@@ -477,6 +477,31 @@ def sdf_head_bwd(d_out, sdf, c, denom, cb=None):
     return zb
 
 
+def dcopy_(dst, src):
+    """dst.copy_(src) for 2-D (or 1-D) fp32 row-major tensors as a KERNEL launch (hm_copy2d_f32).  torch copies
+    contiguous tensors with hipMemcpyAsync, which a graph capture records as a MEMCPY node."""
+    require_gpu(dst, src)
+    if dst.shape != src.shape or dst.dtype != torch.float32 or src.dtype != torch.float32:
+        raise ValueError("hashmod dcopy_: shape / dtype mismatch")
+    d2 = dst if dst.dim() == 2 else dst.reshape(1, -1) if dst.is_contiguous() else None
+    s2 = src if src.dim() == 2 else src.reshape(1, -1) if src.is_contiguous() else None
+    if d2 is None or s2 is None or d2.stride(-1) != 1 or s2.stride(-1) != 1:
+        raise ValueError("hashmod dcopy_: row-major 2-D (or contiguous) tensors only")
+    rows, cols = d2.shape
+    check(lib().hm_copy2d_f32(dptr(d2), _ld(d2), dptr(s2), _ld(s2), rows, cols, stream_ptr(dst)))
+    return dst
+
+
+def cat_rows_(dst, parts, dim):
+    """torch.cat(parts, dim, out=dst) for 2-D fp32 tensors through dcopy_ (no MEMCPY graph nodes)."""
+    o = 0
+    for t in parts:
+        n = t.shape[dim]
+        dcopy_(dst.narrow(dim, o, n), t if t.stride(-1) == 1 else t.contiguous())
+        o += n
+    return dst
+
+
 def colsum_into(x, out):
     """out += column sums of x (no autograd; `out` zeroed by the caller)."""
     require_gpu(x, out)

@@ -55,6 +55,7 @@ class GradAllReducer:
         self.params = [p for p in params if p.requires_grad]
         self.big_numel = big_numel
         self.assume_dense = False   # set by GraphedTrainStep once the iteration is a replayed static graph
+        self.frozen_grads = False   # set with it: the captured optimizer graph reads THESE .grad tensors; never rebind
         self._flat = None
         self._flat_key = None
         self._views = None
@@ -81,6 +82,9 @@ class GradAllReducer:
         works = []
         for p in big:
             if not p.grad.is_contiguous():
+                if self.frozen_grads:
+                    raise RuntimeError("GradAllReducer: a gradient became non-contiguous after the step was captured; "
+                                       "rebinding .grad would detach the captured optimizer graph from it")
                 p.grad = p.grad.contiguous()
             works.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True))
         if small:

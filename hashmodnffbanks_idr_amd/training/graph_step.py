@@ -14,6 +14,7 @@ import os
 
 import torch
 
+from .. import _lib
 from ..model.loss import idr_loss_terms
 
 
@@ -142,6 +143,9 @@ class GraphedTrainStep:
                 self.g_fb, self.g_opt = g_fb, g_opt
                 if self.reducer is not None and hasattr(self.reducer, "assume_dense"):
                     self.reducer.assume_dense = True     # every replay produces every gradient on every rank
+                    self.reducer.frozen_grads = True     # ... into the tensors g_opt was captured on
+                if hasattr(self.opt, "frozen_grads"):
+                    self.opt.frozen_grads = True
                 if dump:
                     g_fb.debug_dump(os.path.join(dump, "g_fb.dot"))
                     g_opt.debug_dump(os.path.join(dump, "g_opt.dot"))
@@ -158,6 +162,9 @@ class GraphedTrainStep:
         if self.reducer is not None:
             self.reducer()
         self.g_opt.replay()
+        # the replayed optimizer wrote the parameters behind torch's back: the packed SDF images now in memory were
+        # built (inside g_fb) from the PREVIOUS values - any eager user (net.sdf, eval, plots) must re-pack
+        _lib.bump_param_epoch()
         if self.sync_each_step:
             # Replays left running ahead of the host, with a device-wide synchronisation somewhere in between,
             # ended in GPU memory faults a few iterations later on ROCm 7.0 ("graph replay fault");

@@ -24,6 +24,7 @@ class ClipAdam(torch.optim.Optimizer):
             raise ValueError("ClipAdam: invalid hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps))
         self.max_norm = max_norm
+        self.frozen_grads = False  # GraphedTrainStep sets it after capture: .grad tensors must keep their addresses
         self._dev_state = {}     # device -> (per-parameter step counters int64[n_params], scratch float[2])
         self.last_grad_norm = None   # device scalar: total gradient norm before clipping (of the last step)
 
@@ -58,6 +59,8 @@ class ClipAdam(torch.optim.Optimizer):
             if not p.is_contiguous():
                 raise ValueError("ClipAdam: parameters must be contiguous")
             if not p.grad.is_contiguous():
+                if self.frozen_grads:
+                    raise RuntimeError("ClipAdam: a gradient became non-contiguous after the step was captured")
                 p.grad = p.grad.contiguous()
             st = self.state[p]
             if not st:
@@ -71,6 +74,7 @@ class ClipAdam(torch.optim.Optimizer):
                                  float(grp["eps"]), float(self.max_norm) if self.max_norm else 0.0,
                                  C.c_void_p(scratch.data_ptr()), _lib.stream_ptr(plist[0][1])))
         self.last_grad_norm = scratch[1]
+        _lib.bump_param_epoch()   # parameters were written through raw pointers: tensor._version did not move
         return loss
 
     # -- torch.optim.Adam-compatible checkpoints ---------------------------------------------------------

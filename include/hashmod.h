@@ -161,8 +161,9 @@ HM_API int hm_sdf_fwd(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const fl
  * sampler_fracs [n_steps] = linspace(0,1,n_steps) (ray_tracing.py:198);
  * steps_u [n_steps]: the U(0,1) fractions shared by all rays (ray_tracing.py:277; training only);
  * outputs: points [N,3], network_object_mask [N] bytes, dists [N];
- * stats_out (optional, 8 device int32): sampler rays, sampler points, secant rays, mask-loss rays,
- *   their points, any-iteration flag, total SDF evaluations, unfinished rays (must be 0).          */
+ * stats_out (optional, 16 device int32): sampler rays, sampler points, secant rays, mask-loss rays,
+ *   their points, any-iteration flag, total SDF evaluations, unfinished rays (must be 0), non-finite SDF
+ *   values met by the search (must be 0), 7 reserved.                                              */
 typedef struct hm_trace_cfg {
     float object_bounding_sphere;
     float sdf_threshold;
@@ -241,6 +242,13 @@ HM_API int hm_sdf_head(int backward, const float *in, int64_t n, int64_t cols, f
 HM_API int hm_colsum(const float *x, int64_t M, int64_t N, int64_t ld, float *out, void *stream);
 /* same, added into out (no zeroing: the caller zeroes all its gradient buffers with one launch)  */
 HM_API int hm_colsum_acc(const float *x, int64_t M, int64_t N, int64_t ld, float *out, void *stream);
+
+/* dst[r*ld_dst + c] = src[r*ld_src + c], r < rows, c < cols, as an ordinary kernel: the copies torch would issue as
+ * hipMemcpyAsync (Tensor.copy_ / clone of contiguous tensors; the saved-activation stacking of the fused MLP-gradient
+ * node, torch.cat in implicit_differentiable_renderer.py:99-100,280-284) become MEMCPY nodes of a captured HIP graph,
+ * which this library keeps out of its captured training iteration (graph replay fault).            */
+HM_API int hm_copy2d_f32(float *dst, int64_t ld_dst, const float *src, int64_t ld_src, int64_t rows, int64_t cols,
+                         void *stream);
 
 /* ---- IDRLoss: value and gradients in one launch (code/model/loss.py:4-70) --------------------------
  * terms[4] = {loss, rgb_loss, eikonal_loss, mask_loss};  d_rgb[n,3], d_sdf[n], d_grad[m,3] = d loss / d input.

@@ -7,14 +7,16 @@ on the host cores).  Parity status: PINNED by tests/test_torch_ref_cpu.py agains
 tests/golden/sdf_*.npz and idr_step_C1.npz.
 
 Arithmetic lives here (hash indices in int64 like the reference, F.linear GEMMs, softplus, the
-clamp); the ray-marching control flow, SampleNetwork, camera helpers and IDRLoss are the package's
-device-agnostic elementwise host logic, which tests/test_raytrace_gpu.py pins against the reference
-separately.  Citations: /root/reference/code/model/...
+clamp); the ray search, SampleNetwork and the camera helpers are oracle/ray_ref.py - nothing of the
+product's control flow is borrowed (only IDRLoss, an elementwise formula pinned by the idr_step fixtures,
+is shared by the tests).  Citations: /root/reference/code/model/...
 """
 import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from . import ray_ref
 
 _PRIMES = torch.tensor([1, 3, 2654435761], dtype=torch.int64)  # embeddings/hashGridEmbedding.py:14
 _CORNERS = torch.tensor([[(n >> d) & 1 for d in range(3)] for n in range(8)], dtype=torch.int64)
@@ -129,26 +131,22 @@ class RefIDR(nn.Module):
 
     def __init__(self, model):
         super().__init__()
-        from hashmodnffbanks_idr_amd.model.ray_tracing import RayTracing
-        from hashmodnffbanks_idr_amd.model.sample_network import SampleNetwork
         imp, ren = model.implicit_network, model.rendering_network
         self.implicit_network = RefImplicit(_grid_from(imp.embed_model.embedder_obj), _lins(imp), imp.skip_in)
         self.rendering_network = RefRendering(_grid_from(ren.embed_model.embedder_obj), _lins(ren))
         rt = model.ray_tracer
-        self.ray_tracer = RayTracing(rt.object_bounding_sphere, rt.sdf_threshold, rt.line_search_step,
-                                     rt.line_step_iters, rt.sphere_tracing_iters, rt.n_steps, rt.n_secant_steps)
-        self.sample_network = SampleNetwork()
+        self.ray_tracer = ray_ref.RayTraceRef(rt.object_bounding_sphere, rt.sdf_threshold, rt.line_search_step,
+                                              rt.line_step_iters, rt.sphere_tracing_iters, rt.n_steps,
+                                              rt.n_secant_steps)
         self.object_bounding_sphere = model.object_bounding_sphere
 
     def forward(self, input):
-        from hashmodnffbanks_idr_amd.utils import rend_util
         object_mask = input["object_mask"].reshape(-1)
-        ray_dirs, cam_loc = rend_util.get_camera_params(input["uv"], input["pose"], input["intrinsics"])
+        ray_dirs, cam_loc = ray_ref.camera_rays(input["uv"], input["pose"], input["intrinsics"])
         B, P, _ = ray_dirs.shape
-        self.ray_tracer.train(self.training)
+        self.ray_tracer.training = self.training
         with torch.no_grad():
-            points, net_mask, dists = self.ray_tracer(sdf=self.implicit_network.sdf, cam_loc=cam_loc,
-                                                      object_mask=object_mask, ray_directions=ray_dirs)
+            points, net_mask, dists = self.ray_tracer(self.implicit_network.sdf, cam_loc, object_mask, ray_dirs)
         points = (cam_loc.unsqueeze(1) + dists.reshape(B, P, 1) * ray_dirs).reshape(-1, 3)
         sdf_output = self.implicit_network(points)[:, 0:1]
         ray_dirs = ray_dirs.reshape(-1, 3)
@@ -160,7 +158,7 @@ class RefIDR(nn.Module):
             pts_all = torch.cat([sp, eik, points.clone().detach()], 0)
             out_s = self.implicit_network(sp)
             g = self.implicit_network.gradient(pts_all)
-            dsp = self.sample_network(sdf_output[sm], out_s[:N, 0:1].detach(), g[:N, 0, :].clone().detach(),
+            dsp = ray_ref.sample_point(sdf_output[sm], out_s[:N, 0:1].detach(), g[:N, 0, :].clone().detach(),
                                       dists[sm].unsqueeze(-1),
                                       cam_loc.unsqueeze(1).repeat(1, P, 1).reshape(-1, 3)[sm], ray_dirs[sm])
             grad_theta = g[N:, 0, :]

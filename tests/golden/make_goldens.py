@@ -81,7 +81,7 @@ def load_embedder(emb, levels, B):
     emb.load_state_dict(sd)
 
 
-def ref_implicit(cfg, hidden, fvs, seed, perturb, table_scale, g_jitter=0.1):
+def ref_implicit(cfg, hidden, fvs, seed, perturb, table_scale, g_jitter=0.1, bias=0.6):
     L, Tt, b, d = P.CONFIGS[cfg]
     net = quiet(ImplicitNetwork, fvs, 3, 1, list(hidden), True, 0.6, [4], True, multires=L,
                 embed_type="HashGrid", log2_max_hash_size=Tt, max_points_per_entry=2,
@@ -89,7 +89,7 @@ def ref_implicit(cfg, hidden, fvs, seed, perturb, table_scale, g_jitter=0.1):
     levels, B, res, rows = P.make_embedder_state(seed, cfg, table_scale)
     load_embedder(net.embed_model.embedder_obj, levels, B)
     E = 3 + 2 * L + 2 * L
-    prm = P.make_sdf_params(seed + 7, E, hidden, 1 + fvs, (4,), 0.6, perturb, g_jitter)
+    prm = P.make_sdf_params(seed + 7, E, hidden, 1 + fvs, (4,), bias, perturb, g_jitter)
     sd = net.state_dict()
     for k, v in prm.items():
         assert sd[k].shape == v.shape, (k, sd[k].shape, v.shape)
@@ -161,14 +161,18 @@ def _sample_idx(shape, k, seed):
     return np.random.RandomState(seed).choice(n, size=min(k, n), replace=False)
 
 
-def gen_sdf():
+def gen_sdf(only=None):
     """SDF MLP forward, gradient(), first-order and double-backward parameter grads."""
     # (a) full width, C1 embedder: outputs + gradient + grad norms / sampled entries
     for tag, cfg, hidden, fvs, perturb, scale, seed, n in [
         ("full", "C1", (512,) * 8, 256, 0.5, 0.5, 31, 128),
         ("init", "C1", (512,) * 8, 256, 0.0, 1e-4, 32, 128),
         ("narrow", "tiny", (64,) * 8, 16, 0.5, 0.5, 33, 256),
+        # the benchmarked width: L=16 -> E=67, layer-3 width 445, skip K = 445 + 67
+        ("C2", "C2", (512,) * 8, 256, 0.5, 0.5, 34, 256),
     ]:
+        if only and tag not in only:
+            continue
         net = ref_implicit(cfg, hidden, fvs, seed, perturb, scale)
         x = P.make_points(seed + 100, n, -1.0, 1.0)
         xt = T(x.copy())
@@ -225,15 +229,19 @@ def _record_uniform():
     return draws, orig
 
 
-def gen_raytrace():
-    for tag, perturb, scale, seed in [("init", 0.0, 1e-4, 41), ("bumpy", 0.1, 0.05, 44)]:
-        net = ref_implicit("C1", (512,) * 8, 256, seed, perturb, scale)
+def gen_raytrace(only=None):
+    # (C2: last-layer bias -1.0 instead of -0.6, so that the perturbed L=16 network keeps a surface: r ~ 0.6 .. 0.8)
+    for tag, cfg, n, perturb, scale, seed, bias in [("init", "C1", 256, 0.0, 1e-4, 41, 0.6),
+                                                    ("bumpy", "C1", 256, 0.1, 0.05, 44, 0.6),
+                                                    ("C2", "C2", 2048, 0.1, 0.05, 45, 1.0)]:
+        if only and tag not in only:
+            continue
+        net = ref_implicit(cfg, (512,) * 8, 256, seed, perturb, scale, bias=bias)
         net.eval()
-        n = 256
         cam, dirs = P.make_rays(seed + 50, n)
         rs = np.random.RandomState(seed + 60)
         # some rays that miss the bounding sphere entirely
-        miss = rs.choice(n, 24, replace=False)
+        miss = rs.choice(n, 24, replace=False)   # (24 of n rays, whatever n is)
         d = dirs[0].copy()
         d[miss[:12]] = -d[miss[:12]]  # behind the camera (t clamps to 0)
         side = np.cross(d[miss[12:]].astype(np.float64), cam[0].astype(np.float64))
@@ -242,7 +250,7 @@ def gen_raytrace():
         object_mask = rs.uniform(0, 1, n) < 0.8
         sdf = lambda p: net(p)[:, 0]  # noqa: E731
         arrays = dict(cam_loc=cam, ray_dirs=dirs, object_mask=object_mask, seed=np.int64(seed),
-                      perturb=np.float64(perturb), table_scale=np.float64(scale))
+                      perturb=np.float64(perturb), table_scale=np.float64(scale), bias=np.float64(bias))
         for mode in ("train", "eval"):
             rt = RayTracing(object_bounding_sphere=1.0, sdf_threshold=5.0e-5, line_search_step=0.5,
                             line_step_iters=3, sphere_tracing_iters=10, n_steps=100, n_secant_steps=8)
@@ -289,10 +297,9 @@ def idr_conf(cfg, hidden=(512,) * 8, fvs=256, rdims=(512,) * 4):
     )
 
 
-def gen_idr_step():
-    """Full IDRNetwork.forward + IDRLoss + backward + 3 Adam steps at config-1 shape (256 rays)."""
-    seed = 51
-    cfg = "C1"
+def gen_idr_step(cfg="C1", n=256, seed=51, n_steps=3, bias=0.6):
+    """Full IDRNetwork.forward + IDRLoss + backward + Adam steps: config-1 shape (256 rays, 3 steps) and the
+    benchmarked config-2 shape (L=16, T=2^19, 2048 rays, 1 step; gen_idr_step_C2)."""
     model = quiet(IDRNetwork, idr_conf(cfg))
     # --- load seeded parameters
     L = P.CONFIGS[cfg][0]
@@ -300,7 +307,7 @@ def gen_idr_step():
     levels, B, _, _ = P.make_embedder_state(seed, cfg, 0.05)
     load_embedder(model.implicit_network.embed_model.embedder_obj, levels, B)
     sd = model.implicit_network.state_dict()
-    for k, v in P.make_sdf_params(seed + 7, E, (512,) * 8, 257, (4,), 0.6, 0.1, 0.1).items():
+    for k, v in P.make_sdf_params(seed + 7, E, (512,) * 8, 257, (4,), bias, 0.1, 0.1).items():
         sd[k] = T(v)
     model.implicit_network.load_state_dict(sd)
     vlevels, vB, _, _ = P.make_embedder_state(seed + 20, "viewdir", 0.5)
@@ -311,7 +318,6 @@ def gen_idr_step():
         sd[k] = T(v)
     model.rendering_network.load_state_dict(sd)
     # --- inputs: identity-K pinhole whose uv reproduce 'uniform-sphere' ray dirs
-    n = 256
     cam, dirs = P.make_rays(seed + 50, n)
     # camera frame: z axis looks at origin
     z = -cam[0] / np.linalg.norm(cam[0])
@@ -333,10 +339,10 @@ def gen_idr_step():
     loss_fn = IDRLoss(eikonal_weight=0.1, mask_weight=100.0, alpha=50.0)
     opt = torch.optim.Adam(model.parameters(), lr=1.0e-4)
     arrays = dict(intrinsics=intr, uv=uv, pose=pose.reshape(1, 4, 4), object_mask=object_mask, rgb_gt=rgb_gt,
-                  seed=np.int64(seed))
+                  seed=np.int64(seed), bias=np.float64(bias))
     model.train()
     names = [k for k, _ in model.named_parameters()]
-    for step in range(3):
+    for step in range(n_steps):
         torch.manual_seed(1000 + step)
         draws, orig = _record_uniform()
         try:
@@ -365,7 +371,7 @@ def gen_idr_step():
                 else:
                     arrays[f"s0:gradnorm:{k}"] = np.float64(p.grad.double().norm().item())
         opt.step()
-        if step in (0, 2):
+        if step in (0, n_steps - 1):
             for k, p in model.named_parameters():
                 v = p.detach().numpy()
                 arrays[f"s{step}:pnorm:{k}"] = np.float64(np.linalg.norm(v.astype(np.float64)))
@@ -373,7 +379,11 @@ def gen_idr_step():
                 arrays[f"s{step}:pidx:{k}"] = idx.astype(np.int64)
                 arrays[f"s{step}:pval:{k}"] = v.reshape(-1)[idx]
     arrays["param_names"] = np.asarray(names)
-    save("idr_step_C1", **arrays)
+    save("idr_step_" + cfg, **arrays)
+
+
+def gen_idr_step_C2():
+    gen_idr_step("C2", 2048, 52, 1, bias=1.0)
 
 
 def gen_init_rng():
@@ -508,12 +518,13 @@ def gen_idr_eval():
          sdf_output=out["sdf_output"].detach().numpy(), network_object_mask=out["network_object_mask"].numpy())
 
 
-GENS = dict(idr_eval=gen_idr_eval, nffb=gen_nffb, levels=gen_levels, hash_ids=gen_hash_ids, encode=gen_encode, encode_bwd=gen_encode_bwd,
+GENS = dict(sdf_C2=lambda: gen_sdf(("C2",)), raytrace_C2=lambda: gen_raytrace(("C2",)), idr_step_C2=gen_idr_step_C2,
+            idr_eval=gen_idr_eval, nffb=gen_nffb, levels=gen_levels, hash_ids=gen_hash_ids, encode=gen_encode, encode_bwd=gen_encode_bwd,
             sdf=gen_sdf, raytrace=gen_raytrace, idr_step=gen_idr_step, init_rng=gen_init_rng,
             camera=gen_camera)
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or list(GENS)
+    which = sys.argv[1:] or [k for k in GENS if k not in ("sdf_C2", "raytrace_C2")]   # (subsets of sdf / raytrace)
     for w in which:
         print(f"== {w}")
         GENS[w]()

@@ -46,7 +46,7 @@ def load_embedder(emb, levels, B):
     emb.load_state_dict(sd)
 
 
-def make_implicit(cfg, hidden, fvs, seed, perturb, table_scale, g_jitter=0.1, device="cuda"):
+def make_implicit(cfg, hidden, fvs, seed, perturb, table_scale, g_jitter=0.1, device="cuda", bias=0.6):
     from hashmodnffbanks_idr_amd.model.implicit_differentiable_renderer import ImplicitNetwork
     L, Tt, b, d = P.CONFIGS[cfg]
     net = ImplicitNetwork(fvs, 3, 1, list(hidden), True, 0.6, [4], True, multires=L, embed_type="HashGrid",
@@ -55,10 +55,30 @@ def make_implicit(cfg, hidden, fvs, seed, perturb, table_scale, g_jitter=0.1, de
     levels, B, res, rows = P.make_embedder_state(seed, cfg, table_scale)
     load_embedder(net.embed_model.embedder_obj, levels, B)
     E = 3 + 4 * L
-    prm = P.make_sdf_params(seed + 7, E, hidden, 1 + fvs, (4,), 0.6, perturb, g_jitter)
+    prm = P.make_sdf_params(seed + 7, E, hidden, 1 + fvs, (4,), bias, perturb, g_jitter)
     sd = net.state_dict()
     for k, v in prm.items():
         assert sd[k].shape == v.shape, (k, sd[k].shape, v.shape)
         sd[k] = torch.from_numpy(v)
     net.load_state_dict(sd)
     return net.to(device)
+
+
+def make_idr(cfg, seed, bias=0.6, device="cuda"):
+    """IDRNetwork with the seeded parameters make_goldens.gen_idr_step / gen_idr_eval gave the reference."""
+    from hashmodnffbanks_idr_amd.model.implicit_differentiable_renderer import IDRNetwork
+    model = IDRNetwork(idr_conf(cfg))
+    L = P.CONFIGS[cfg][0]
+    levels, B, _, _ = P.make_embedder_state(seed, cfg, 0.05)
+    load_embedder(model.implicit_network.embed_model.embedder_obj, levels, B)
+    sd = model.implicit_network.state_dict()
+    for k, v in P.make_sdf_params(seed + 7, 3 + 4 * L, (512,) * 8, 257, (4,), bias, 0.1, 0.1).items():
+        sd[k] = torch.from_numpy(v)
+    model.implicit_network.load_state_dict(sd)
+    vl, vB, _, _ = P.make_embedder_state(seed + 20, "viewdir", 0.5)
+    load_embedder(model.rendering_network.embed_model.embedder_obj, vl, vB)
+    sd = model.rendering_network.state_dict()
+    for k, v in P.make_render_params(seed + 9).items():
+        sd[k] = torch.from_numpy(v)
+    model.rendering_network.load_state_dict(sd)
+    return model.to(device)

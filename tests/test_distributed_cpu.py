@@ -37,7 +37,7 @@ def _build():
         model.implicit_network.embed_model.embedder_obj.table.uniform_(-0.3, 0.3)
     ref = R.RefIDR(model)
     ref.train()
-    ref.ray_tracer.steps_override = torch.linspace(0.01, 0.99, 100)
+    ref.ray_tracer.steps = torch.linspace(0.01, 0.99, 100)
     inp, gt = bench.synthetic_batch(5, 64, "cpu")
     rs = np.random.RandomState(3)
     inp["object_mask"] = torch.from_numpy(rs.uniform(0, 1, (1, 64)) < 0.8)

@@ -102,6 +102,17 @@ def test_graph_contains_no_memset_or_memcpy_nodes_of_ours(tmp_path):
     kinds = re.findall(r'label="\{\s*\n?(\w+)\n', dot)
     assert kinds.count("KERNEL") > 100
     assert kinds.count("MEMSET") == 0, "a MEMSET node is back in the captured iteration"
+    # every node of the chain with what surrounds it: names the op that recorded a copy node, should one come back
+    nodes = re.findall(r'"(graph_\d+_node_\d+)"\[[^\]]*?label="\{\s*\n?(\w+)\n([^"]*)"', dot)
+    def short(body):
+        m = re.search(r"\| (_Z\w+)", body)
+        return m.group(1)[:90] if m else re.sub(r"\s+", " ", body)[:160]
+    copies = [i for i, n in enumerate(nodes) if n[1] != "KERNEL"]
+    for i in copies:
+        print(f"non-kernel node {nodes[i][1]}: {short(nodes[i][2])}")
+        print(f"    after  {short(nodes[i - 1][2]) if i else '-'}")
+        print(f"    before {short(nodes[i + 1][2]) if i + 1 < len(nodes) else '-'}")
+    assert kinds.count("MEMCPY") == 0, f"{kinds.count('MEMCPY')} MEMCPY nodes in the captured iteration"
     edges = re.findall(r'"(graph_\d+_node_\d+)"\s*->\s*"(graph_\d+_node_\d+)"', dot)
     assert len(edges) == len(kinds) - 1, "captured iteration is no longer a single chain"
     opt_dot = open(tmp_path / "g_opt.dot").read()
@@ -126,3 +137,45 @@ def test_run_ahead_replays_with_a_device_sync_in_between():
     assert np.isfinite(lo["loss"].item())
     assert st["rays"] == 512 and st["unfinished"] == 0 and 0 <= st["sampler_rays"] <= 512
     assert 512 <= st["sdf_evals"] <= 512 * 2 * 41 + 512 * 208
+
+
+def _sdf_matches_layerwise(net, x):
+    """fused no-grad kernel (packed weight images) vs the layer-wise GEMM path (live parameters)"""
+    with torch.no_grad():
+        fused = net.sdf(x)
+    with torch.enable_grad():
+        layer = net(x)[:, 0].detach()      # parameters require grad -> the GEMM route, never the packed images
+    err = (fused - layer).abs().max().item()
+    assert err <= 1e-5, f"fused SDF kernel uses stale packed weights: max |d| = {err:.3e}"
+
+
+def test_packed_weights_follow_clipadam_updates_eager():
+    """ClipAdam writes the parameters through raw pointers (tensor._version does not move): the packed images of
+    the fused SDF kernel must still be rebuilt after every step (cache keyed on _version only)."""
+    from hashmodnffbanks_idr_amd import parallel
+    from hashmodnffbanks_idr_amd.training.optim import ClipAdam
+    model, loss_fn, inp, gt = _setup()
+    net = model.implicit_network
+    x = (torch.rand(777, 3, device="cuda") * 2 - 1)
+    _sdf_matches_layerwise(net, x)
+    opt = ClipAdam(model.parameters(), lr=2e-3, max_norm=1.0)      # large steps: stale images would be far off
+    torch.manual_seed(9)
+    for _ in range(3):
+        parallel.train_step(model, loss_fn, opt, inp, gt)
+        _sdf_matches_layerwise(net, x)
+
+
+def test_packed_weights_follow_graph_replays():
+    """After graph replays (which never run Python) an eager net.sdf() must see the LAST optimizer update."""
+    from hashmodnffbanks_idr_amd.training.graph_step import GraphedTrainStep
+    from hashmodnffbanks_idr_amd.training.optim import ClipAdam
+    model, loss_fn, inp, gt = _setup()
+    net = model.implicit_network
+    x = (torch.rand(777, 3, device="cuda") * 2 - 1)
+    stepper = GraphedTrainStep(model, loss_fn, ClipAdam(model.parameters(), lr=2e-3, max_norm=1.0), warmup=2)
+    torch.manual_seed(9)
+    for i in range(6):
+        stepper.step(inp, gt)
+        if i >= 1:
+            _sdf_matches_layerwise(net, x)
+    assert stepper.g_fb is not None

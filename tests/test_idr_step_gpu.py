@@ -1,108 +1,124 @@
-"""Full IDRNetwork.forward + IDRLoss + backward + Adam on 256 synthetic rays (config-1 shape)
-against the values captured from the reference run (tests/golden/idr_step_C1.npz)."""
+"""Full IDRNetwork.forward + IDRLoss + backward + Adam against the values captured from the reference run:
+config-1 shape (256 rays, 3 steps; tests/golden/idr_step_C1.npz) and the benchmarked config-2 shape
+(L=16, T=2^19 -> E=67, 2048 rays, 1 step; idr_step_C2.npz), eager and as the captured HIP graph."""
 import numpy as np
 import pytest
 import torch
 
-import params as P
-from helpers import idr_conf, load_embedder
+from helpers import make_idr
 
 pytestmark = pytest.mark.gpu
 
+CASES = [("C1", 3), ("C2", 1)]
 
-def _model(seed):
-    from hashmodnffbanks_idr_amd.model.implicit_differentiable_renderer import IDRNetwork
-    cfg = "C1"
-    model = IDRNetwork(idr_conf(cfg))
-    L = P.CONFIGS[cfg][0]
-    levels, B, _, _ = P.make_embedder_state(seed, cfg, 0.05)
-    load_embedder(model.implicit_network.embed_model.embedder_obj, levels, B)
-    sd = model.implicit_network.state_dict()
-    for k, v in P.make_sdf_params(seed + 7, 3 + 4 * L, (512,) * 8, 257, (4,), 0.6, 0.1, 0.1).items():
-        sd[k] = torch.from_numpy(v)
-    model.implicit_network.load_state_dict(sd)
-    vl, vB, _, _ = P.make_embedder_state(seed + 20, "viewdir", 0.5)
-    load_embedder(model.rendering_network.embed_model.embedder_obj, vl, vB)
-    sd = model.rendering_network.state_dict()
-    for k, v in P.make_render_params(seed + 9).items():
-        sd[k] = torch.from_numpy(v)
-    model.rendering_network.load_state_dict(sd)
-    return model.cuda()
+
+def _model(g, cfg):
+    return make_idr(cfg, int(g["seed"]), float(g["bias"]) if "bias" in g.files else 0.6)
 
 
 def _close_mostly(a, b, rtol, atol, max_bad=0.005, what=""):
     """The SDF is discontinuous across voxel faces (hash features are piecewise constant in the
     reference's frac mode), so a ray point that differs in the last bits may sit in the neighbouring
-    voxel: allow a tiny fraction of outliers, everything else tight."""
-    bad = np.abs(a - b) > atol + rtol * np.abs(b)
-    assert bad.mean() <= max_bad, f"{what}: {bad.sum()} / {bad.size} outside tolerance, max {np.abs(a - b).max()}"
+    voxel: allow a tiny fraction of outliers, everything else tight.  Prints the observed error."""
+    err = np.abs(a - b)
+    bad = err > atol + rtol * np.abs(b)
+    rel = err / (np.abs(b) + atol / max(rtol, 1e-30))
+    print(f"    {what}: max |d| {err.max():.3e}, max |d|/(|ref| + atol/rtol) {rel.max():.3e} (rtol {rtol:g}), "
+          f"{int(bad.sum())} / {bad.size} outside")
+    assert bad.mean() <= max_bad, f"{what}: {bad.sum()} / {bad.size} outside tolerance, max {err.max()}"
 
 
+def _check_first_step(g, out, lo, gn, model, n_rays, tag):
+    """Everything the reference recorded for its first iteration.  Rays whose network_object_mask differs from the
+    reference's (a threshold decision on SDF values that differ in the last bits; at most 2 allowed) are masked
+    out of the per-ray comparisons and widen the tolerance of the sums they enter - the checks ALWAYS run."""
+    ref_mask = g["s0:network_object_mask"]
+    flip = out["network_object_mask"].cpu().numpy() != ref_mask
+    mism = int(flip.sum())
+    print(f"[{tag}] network_object_mask mismatches: {mism} / {ref_mask.size}")
+    assert mism <= 2, f"{mism} network_object_mask mismatches"
+    keep = ~flip
+    per_ray = mism / float(n_rays)
+    for k, share in (("loss", 8.0), ("rgb_loss", 4.0), ("eikonal_loss", 2.0), ("mask_loss", 8.0)):
+        ref = float(g[f"s0:{k}"])
+        rel = abs(lo[k].item() - ref) / (abs(ref) + 1e-12)
+        print(f"    {k}: {lo[k].item():.7g} vs {ref:.7g}  rel {rel:.2e}")
+        assert abs(lo[k].item() - ref) <= (2e-4 + share * per_ray) * abs(ref) + 1e-6, (k, lo[k].item(), ref)
+    ref_gn = float(g["s0:total_grad_norm"])
+    print(f"    total grad norm: {gn:.6g} vs {ref_gn:.6g}  rel {abs(gn - ref_gn) / ref_gn:.2e}")
+    assert abs(gn - ref_gn) <= (2e-3 + 8.0 * per_ray) * ref_gn, (gn, ref_gn)
+    n_eik = n_rays // 2
+    keep_g = np.concatenate([np.ones(n_eik, bool), keep])      # grad_theta rows: eikonal samples, then the ray points
+    _close_mostly(out["sdf_output"].detach().cpu().numpy()[keep], g["s0:sdf_output"][keep], 1e-4, 2e-5,
+                  what="sdf_output")
+    _close_mostly(out["grad_theta"].detach().cpu().numpy()[keep_g], g["s0:grad_theta"][keep_g], 1e-3, 2e-4,
+                  what="grad_theta")
+    _close_mostly(out["rgb_values"].detach().cpu().numpy()[keep], g["s0:rgb_values"][keep], 1e-3, 2e-4,
+                  what="rgb_values")
+    emb = model.implicit_network.embed_model.embedder_obj
+    off = emb.desc.row_off
+    gtol = 5e-3 + 8.0 * per_ray
+    worst = 0.0
+    for name, p in model.named_parameters():
+        if name.endswith("implicit_network.embed_model.embedder_obj.table"):
+            for l in range(emb.n_levels):
+                ref = float(g["s0:gradnorm:implicit_network.embed_model.embedder_obj.levels."
+                              f"{l}.embedding.weight"])
+                got = p.grad[int(off[l]):int(off[l + 1])].double().norm().item()
+                worst = max(worst, abs(got - ref) / (ref + 1e-30))
+                assert abs(got - ref) <= gtol * ref + 1e-9, (name, l, got, ref)
+        elif name.endswith("embedder_obj.table"):
+            continue
+        else:
+            ref = float(g[f"s0:gradnorm:{name}"])
+            if ref < 0:
+                assert p.grad is None
+                continue
+            got = p.grad.double().norm().item()
+            worst = max(worst, abs(got - ref) / (ref + 1e-30))
+            assert abs(got - ref) <= gtol * ref + 1e-9, (name, got, ref)
+    print(f"    per-parameter gradient norms: worst rel {worst:.2e} (tolerance {gtol:.1e})")
+    return mism
+
+
+@pytest.mark.parametrize("cfg,n_steps", CASES)
 @pytest.mark.parametrize("merge", [True, False])
-def test_idr_training_steps(golden, merge):
+def test_idr_training_steps(golden, merge, cfg, n_steps):
     """merge=False runs the reference's exact evaluation structure (three SDF-network evaluations of the
     ray points); merge=True the single merged evaluation - both must reproduce the reference run."""
     from hashmodnffbanks_idr_amd.model.loss import IDRLoss
-    g = golden("idr_step_C1")
-    model = _model(int(g["seed"]))
+    g = golden(f"idr_step_{cfg}")
+    model = _model(g, cfg)
     model.merge_evaluations = merge
     model.train()
     inp = {k: torch.from_numpy(g[k]).cuda() for k in ("intrinsics", "uv", "pose", "object_mask")}
     gt = {"rgb": torch.from_numpy(g["rgb_gt"]).cuda()}
+    n_rays = g["uv"].shape[1]
     loss_fn = IDRLoss(eikonal_weight=0.1, mask_weight=100.0, alpha=50.0)
     opt = torch.optim.Adam(model.parameters(), lr=1.0e-4)
-    emb = model.implicit_network.embed_model.embedder_obj
-    for step in range(3):
+    for step in range(n_steps):
         torch.manual_seed(1000 + step)  # same CPU RNG stream as the reference run: steps, then eikonal points
         out = model(inp)
         lo = loss_fn(out, gt)
         opt.zero_grad()
         lo["loss"].backward()
         gn = torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
-        ref_mask = g[f"s{step}:network_object_mask"]
-        mism = (out["network_object_mask"].cpu().numpy() != ref_mask).sum()
         if step == 0:
-            # identical parameters: everything must agree tightly
-            assert mism <= 2, f"step {step}: {mism} network_object_mask mismatches"
-            if mism == 0:
-                for k in ("loss", "rgb_loss", "eikonal_loss", "mask_loss"):
-                    ref = float(g[f"s{step}:{k}"])
-                    assert abs(lo[k].item() - ref) <= 2e-4 * abs(ref) + 1e-6, (step, k, lo[k].item(), ref)
-                ref_gn = float(g[f"s{step}:total_grad_norm"])
-                assert abs(gn.item() - ref_gn) <= 2e-3 * ref_gn, (step, gn.item(), ref_gn)
-                _close_mostly(out["sdf_output"].detach().cpu().numpy(), g[f"s{step}:sdf_output"], 1e-4, 2e-5,
-                              what="sdf_output")
-                _close_mostly(out["grad_theta"].detach().cpu().numpy(), g[f"s{step}:grad_theta"], 1e-3, 2e-4,
-                              what="grad_theta")
-                _close_mostly(out["rgb_values"].detach().cpu().numpy(), g[f"s{step}:rgb_values"], 1e-3, 2e-4,
-                              what="rgb_values")
-                off = emb.desc.row_off
-                for name, p in model.named_parameters():
-                    if name.endswith("implicit_network.embed_model.embedder_obj.table"):
-                        for l in range(emb.n_levels):
-                            ref = float(g["s0:gradnorm:implicit_network.embed_model.embedder_obj.levels."
-                                          f"{l}.embedding.weight"])
-                            got = p.grad[int(off[l]):int(off[l + 1])].double().norm().item()
-                            assert abs(got - ref) <= 5e-3 * ref + 1e-9, (name, l, got, ref)
-                    elif name.endswith("embedder_obj.table"):
-                        continue
-                    else:
-                        ref = float(g[f"s0:gradnorm:{name}"])
-                        if ref < 0:
-                            assert p.grad is None
-                            continue
-                        got = p.grad.double().norm().item()
-                        assert abs(got - ref) <= 5e-3 * ref + 1e-9, (name, got, ref)
+            mism = _check_first_step(g, out, lo, gn.item(), model, n_rays, f"{cfg} eager merge={merge}")
         else:
             # Adam's first updates are lr*sign(g): a gradient entry at noise level may flip sign, so the
             # trajectories separate by O(lr) in a few weights; require loss-curve agreement instead.
-            assert mism <= 0.05 * ref_mask.size, f"step {step}: {mism} mask mismatches"
+            ref_mask = g[f"s{step}:network_object_mask"]
+            mism_s = (out["network_object_mask"].cpu().numpy() != ref_mask).sum()
+            assert mism_s <= 0.05 * ref_mask.size, f"step {step}: {mism_s} mask mismatches"
             for k in ("loss", "eikonal_loss", "mask_loss"):
                 ref = float(g[f"s{step}:{k}"])
                 assert abs(lo[k].item() - ref) <= 0.03 * abs(ref) + 1e-4, (step, k, lo[k].item(), ref)
         opt.step()
-        if step == 0 and mism == 0:
+        if step == 0:
             # parameters after one Adam step (lr 1e-4): sampled entries, allow a handful of sign flips
+            # (more of them when a ray took the other branch: its gradient share moves entries at noise level)
+            worst = 0.0
             for name, p in model.named_parameters():
                 if name.endswith("embedder_obj.table"):
                     continue
@@ -110,21 +126,53 @@ def test_idr_training_steps(golden, merge):
                 ref = g[f"s0:pval:{name}"]
                 got = p.detach().cpu().numpy().reshape(-1)[idx]
                 bad = np.abs(got - ref) > 2e-6 + 1e-5 * np.abs(ref)
-                assert bad.mean() <= 0.05, (name, bad.sum(), np.abs(got - ref).max())
+                worst = max(worst, float(bad.mean()))
+                assert bad.mean() <= (0.05 if mism == 0 else 0.25), (name, bad.sum(), np.abs(got - ref).max())
                 assert np.abs(got - ref).max() <= 2.5e-4, name
+            print(f"    parameters after one Adam step: worst fraction of sampled entries off by a sign flip {worst:.3f}")
+
+
+def test_graphed_step_C2_matches_reference(golden):
+    """ONE captured-graph iteration at the benchmarked configuration (C2, 2048 rays) against the reference's own
+    first iteration on the same random draws.  lr = 0 keeps the parameters at their initial values through the two
+    eager warm-up iterations and the capture, and the CPU generator is re-seeded before every step, so the first
+    REPLAYED iteration computes exactly what the reference's step 0 did."""
+    from hashmodnffbanks_idr_amd.model.loss import IDRLoss
+    from hashmodnffbanks_idr_amd.training.graph_step import GraphedTrainStep
+    from hashmodnffbanks_idr_amd.training.optim import ClipAdam
+    g = golden("idr_step_C2")
+    model = _model(g, "C2")
+    model.train()
+    inp = {k: torch.from_numpy(g[k]).cuda() for k in ("intrinsics", "uv", "pose", "object_mask")}
+    gt = {"rgb": torch.from_numpy(g["rgb_gt"]).cuda()}
+    n_rays = g["uv"].shape[1]
+    loss_fn = IDRLoss(eikonal_weight=0.1, mask_weight=100.0, alpha=50.0)
+    opt = ClipAdam(model.parameters(), lr=0.0, max_norm=1.0)
+    stepper = GraphedTrainStep(model, loss_fn, opt, warmup=2)
+    for it in range(4):
+        torch.manual_seed(1000)
+        out, lo = stepper.step(inp, gt)
+    assert stepper.g_fb is not None, "graph capture fell back to eager"
+    torch.cuda.synchronize()
+    assert np.array_equal(stepper.static["steps"].cpu().numpy(), g["s0:draw0"])       # the reference's two draws
+    assert np.array_equal(stepper.static["eik"].cpu().numpy(), g["s0:draw1"])
+    st = model.ray_tracer.last_stats
+    assert st["unfinished"] == 0 and st.get("nonfinite", 0) == 0
+    _check_first_step(g, out, lo, float(opt.last_grad_norm.item()), model, n_rays, "C2 captured graph")
 
 
 def test_idr_eval_forward(golden):
     """model.eval(); model(input) - the contract evaluation/eval.py relies on (grad_theta is None)."""
     g = golden("idr_eval_C1")
-    model = _model(int(g["seed"]))
+    model = _model(g, "C1")
     model.eval()
     inp = {k: torch.from_numpy(g[k]).cuda() for k in ("intrinsics", "uv", "pose", "object_mask")}
     out = model(inp)
     assert out["grad_theta"] is None
-    mism = (out["network_object_mask"].cpu().numpy() != g["network_object_mask"]).sum()
-    assert mism <= 2
-    if mism == 0:
-        _close_mostly(out["points"].detach().cpu().numpy(), g["points"], 1e-4, 2e-5, what="points")
-        _close_mostly(out["sdf_output"].detach().cpu().numpy(), g["sdf_output"], 1e-4, 2e-5, what="sdf_output")
-        _close_mostly(out["rgb_values"].detach().cpu().numpy(), g["rgb_values"], 1e-3, 2e-4, what="rgb_values")
+    flip = out["network_object_mask"].cpu().numpy() != g["network_object_mask"]
+    print(f"eval forward: {int(flip.sum())} network_object_mask mismatches")
+    assert flip.sum() <= 2
+    keep = ~flip
+    _close_mostly(out["points"].detach().cpu().numpy()[keep], g["points"][keep], 1e-4, 2e-5, what="points")
+    _close_mostly(out["sdf_output"].detach().cpu().numpy()[keep], g["sdf_output"][keep], 1e-4, 2e-5, what="sdf_output")
+    _close_mostly(out["rgb_values"].detach().cpu().numpy()[keep], g["rgb_values"][keep], 1e-3, 2e-4, what="rgb_values")

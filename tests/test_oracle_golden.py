@@ -99,3 +99,31 @@ def test_sphere_intersection(golden):
     t2, m = O.sphere_intersection(g["cam_loc"], g["ray_dirs"], 1.0)
     assert np.array_equal(m, g["mask_intersect"].reshape(-1))
     np.testing.assert_allclose(t2, g["sphere_intersections"].reshape(-1, 2), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag,cfg", [("init", "C1"), ("bumpy", "C1"), ("C2", "C2")])
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_ray_ref_golden(golden, tag, cfg, mode):
+    """oracle/ray_ref.py (the ray search restated independently of the product) against the reference's own
+    RayTracing.forward outputs: masks exact, distances / points to fp32 round-off, same number of SDF evaluations.
+    The SDF callable is oracle/torch_ref.RefImplicit on the CPU (torch sgemm, like the reference run)."""
+    import torch
+    from helpers import make_implicit
+    from oracle import ray_ref, torch_ref as R
+    g = golden(f"raytrace_{tag}")
+    net = make_implicit(cfg, (512,) * 8, 256, int(g["seed"]), float(g["perturb"]), float(g["table_scale"]),
+                        device="cpu", bias=float(g["bias"]) if "bias" in g.files else 0.6)
+    sdf_net = R.RefImplicit(R._grid_from(net.embed_model.embedder_obj), R._lins(net), net.skip_in)
+    torch.set_num_threads(8)
+    rt = ray_ref.RayTraceRef(1.0, 5.0e-5, 0.5, 3, 10, 100, 8)
+    rt.training = mode == "train"
+    rt.steps = torch.from_numpy(g["steps"])
+    with torch.no_grad():
+        pts, mask, t = rt(sdf_net.sdf, torch.from_numpy(g["cam_loc"]), torch.from_numpy(g["object_mask"]),
+                          torch.from_numpy(g["ray_dirs"]))
+    flips = int((mask.numpy() != g[f"{mode}_mask"]).sum())
+    assert flips <= 1, flips                      # (one ray on a threshold may flip with the BLAS thread count)
+    same = mask.numpy() == g[f"{mode}_mask"]
+    np.testing.assert_allclose(t.numpy()[same], g[f"{mode}_dists"][same], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(pts.numpy()[same], g[f"{mode}_points"][same], rtol=2e-5, atol=5e-6)
+    assert abs(rt.sdf_evals - int(g[f"{mode}_sdf_evals"])) <= 0.01 * int(g[f"{mode}_sdf_evals"])

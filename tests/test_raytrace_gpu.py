@@ -9,9 +9,18 @@ from helpers import make_implicit
 pytestmark = pytest.mark.gpu
 
 
-def _run(g, mode):
+def _cfg(tag):
+    return "C2" if tag == "C2" else "C1"
+
+
+def _net(g, tag):
+    return make_implicit(_cfg(tag), (512,) * 8, 256, int(g["seed"]), float(g["perturb"]), float(g["table_scale"]),
+                         bias=float(g["bias"]) if "bias" in g.files else 0.6)
+
+
+def _run(g, mode, tag="init"):
     from hashmodnffbanks_idr_amd.model.ray_tracing import RayTracing
-    net = make_implicit("C1", (512,) * 8, 256, int(g["seed"]), float(g["perturb"]), float(g["table_scale"]))
+    net = _net(g, tag)
     net.eval()
     rt = RayTracing(object_bounding_sphere=1.0, sdf_threshold=5.0e-5, line_search_step=0.5, line_step_iters=3,
                     sphere_tracing_iters=10, n_steps=100, n_secant_steps=8).cuda()
@@ -30,16 +39,18 @@ def _run(g, mode):
     return pts.cpu().numpy(), mask.cpu().numpy(), dists.cpu().numpy(), sum(evals)
 
 
-@pytest.mark.parametrize("tag", ["init", "bumpy"])
+@pytest.mark.parametrize("tag", ["init", "bumpy", "C2"])   # C2: the benchmarked configuration, 2048 rays
 @pytest.mark.parametrize("mode", ["train", "eval"])
 def test_raytracing_golden(golden, tag, mode):
     g = golden(f"raytrace_{tag}")
-    pts, mask, dists, n_evals = _run(g, mode)
+    pts, mask, dists, n_evals = _run(g, mode, tag)
     ref_mask, ref_d, ref_p = g[f"{mode}_mask"], g[f"{mode}_dists"], g[f"{mode}_points"]
     # The SDF values differ from the reference's CPU GEMM in the last bits, and every decision of the
     # tracer is a threshold on them (sdf > 5e-5, sign changes), so a ray sitting exactly on a
     # threshold may legitimately take the other branch: allow <= 1 % such rays, everything else tight.
     mism = mask != ref_mask
+    print(f"raytrace {tag}/{mode}: {mism.sum()} / {mism.size} mask mismatches, {n_evals} SDF evaluations "
+          f"(reference {int(g[f'{mode}_sdf_evals'])}), hits {int(mask.sum())}")
     assert mism.mean() <= 0.01, f"{mism.sum()} mask mismatches"
     same = ~mism
     dd = np.abs(dists - ref_d)[same]
@@ -62,15 +73,15 @@ def test_sphere_intersection_golden(golden):
     np.testing.assert_allclose(t.cpu().numpy(), g["sphere_intersections"], rtol=1e-6, atol=1e-6)
 
 
-def _device_vs_host(tag, golden, mode, n_rays=None, seed=0):
+def _device_vs_host(tag, golden, mode, n_rays=None, seed=0, tile=64):
     """The sync-free device tracer must reproduce the generic (torch op) tracer when both use the
     same SDF kernel tile size (so the SDF values are bit-identical)."""
     from hashmodnffbanks_idr_amd.model.ray_tracing import RayTracing
     import params as P
     g = golden(f"raytrace_{tag}")
-    net = make_implicit("C1", (512,) * 8, 256, int(g["seed"]), float(g["perturb"]), float(g["table_scale"]))
+    net = _net(g, tag)
     net.eval()
-    net.sdf_tile_points = 64
+    net.sdf_tile_points = tile
     if n_rays is None:
         cam, dirs, om = g["cam_loc"], g["ray_dirs"], g["object_mask"]
     else:
@@ -104,6 +115,16 @@ def test_device_tracer_equals_generic_tracer(golden, tag, mode):
 def test_device_tracer_equals_generic_tracer_2048_rays(golden):
     st = _device_vs_host("bumpy", golden, "train", n_rays=2048, seed=11)
     assert st["sdf_evals"] > 2048 * 20
+
+
+@pytest.mark.parametrize("tile", [0, 64])
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_device_tracer_equals_generic_tracer_C2(golden, mode, tile):
+    """Benchmarked configuration (L=16, T=2^19 -> E=67), 2048 rays.  tile 0 = the tile size is chosen per call from the
+    live point count: on the host by the generic tracer, on the device by the sync-free one - the same rule, so the
+    two searches must still agree bit for bit."""
+    st = _device_vs_host("C2", golden, mode, tile=tile)
+    assert st["sdf_evals"] > 2048 * 10 and st.get("nonfinite", 0) == 0
 
 
 @pytest.mark.parametrize("case", ["one_ray", "all_miss_sphere", "mask_all_false", "mask_all_true", "odd_count"])

@@ -10,7 +10,7 @@ from oracle import c_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-CASES = [("full", "C1"), ("init", "C1"), ("narrow", "tiny")]
+CASES = [("full", "C1"), ("init", "C1"), ("narrow", "tiny"), ("C2", "C2")]   # C2 = the benchmarked width (E = 67)
 
 
 def _net(g, cfg):
@@ -55,6 +55,42 @@ def test_fused_forward_vs_oracle_ragged(golden, n, tile):
     _close(sdf, ref[:, 0], what="sdf-only vs oracle")
     if full is not None:
         _close(full, ref[:200], what="full vs oracle")
+
+
+_C2_ORACLE = {}
+
+
+def _c2_oracle(g, n):
+    """C oracle at the benchmarked configuration (L=16, T=2^19 -> E=67, layer 3 = 445 wide, skip K = 445+67),
+    evaluated once per batch size and shared by the tile-size cases."""
+    if n not in _C2_ORACLE:
+        L, T, b, d = P.CONFIGS["C2"]
+        seed = int(g["seed"])
+        levels, B, _, _ = P.make_embedder_state(seed, "C2", float(g["table_scale"]))
+        prm = P.make_sdf_params(seed + 7, 3 + 4 * L, (512,) * 8, 257, (4,), 0.6, float(g["perturb"]), 0.1)
+        orc = O.SdfOracle(O.Grid(L, T, b, d), np.concatenate(levels, 0), B, prm)
+        x = P.make_points(n + 1, n, -1.05, 1.05)
+        _C2_ORACLE[n] = (x, orc(x))
+    return _C2_ORACLE[n]
+
+
+@pytest.mark.parametrize("tile", [0, 4, 8, 16, 64])
+@pytest.mark.parametrize("n", [1, 17, 65, 2049, 4097, 64 * 300 + 5])
+def test_fused_forward_vs_oracle_ragged_C2(golden, n, tile):
+    """Every tile size of the fused kernel at the bench configuration, value by value against the oracle
+    (rtol 1e-5): different k padding of both packed images than C1 (E = 67 -> 9 octets / 5 16-blocks)."""
+    g = golden("sdf_C2")
+    net = _net(g, "C2")
+    net.sdf_tile_points = tile
+    x, ref = _c2_oracle(g, n)
+    with torch.no_grad():
+        sdf = net.sdf(torch.from_numpy(x).cuda()).cpu().numpy()
+        full = net(torch.from_numpy(x[:300]).cuda()).cpu().numpy() if n >= 300 else None
+    err = np.abs(sdf - ref[:, 0]) / (np.abs(ref[:, 0]) + 2e-6 / 1e-5)
+    print(f"C2 fused sdf n={n} tile={tile}: max |d| / (|ref| + 0.2) = {err.max():.3e}")
+    _close(sdf, ref[:, 0], what="sdf-only vs oracle (C2)")
+    if full is not None:
+        _close(full, ref[:300], what="full vs oracle (C2)")
 
 
 @pytest.mark.parametrize("tag,cfg", CASES)

@@ -4,8 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-import params as P
-from helpers import idr_conf, load_embedder, make_implicit
+from helpers import make_implicit
 from oracle import torch_ref as R
 
 
@@ -35,7 +34,7 @@ def _check(net, g, label):
             np.testing.assert_allclose(arr, g[key + ":full"], rtol=1e-4, atol=1e-4 * max(np.abs(g[key + ":full"]).max(), 1e-12))
 
 
-@pytest.mark.parametrize("tag,cfg", [("narrow", "tiny"), ("full", "C1")])
+@pytest.mark.parametrize("tag,cfg", [("narrow", "tiny"), ("full", "C1"), ("C2", "C2")])
 def test_sdf_grads(golden, tag, cfg):
     g = golden(f"sdf_{tag}")
     net = _ref_implicit(g, cfg)
@@ -54,28 +53,16 @@ def test_sdf_grads(golden, tag, cfg):
     _check(net, g, "g2")
 
 
-def test_idr_step0(golden):
-    from hashmodnffbanks_idr_amd.model.implicit_differentiable_renderer import IDRNetwork
+@pytest.mark.parametrize("cfg", ["C1", "C2"])      # C2 = the benchmarked configuration, 2048 rays
+def test_idr_step0(golden, cfg):
+    from helpers import make_idr
     from hashmodnffbanks_idr_amd.model.loss import IDRLoss
-    g = golden("idr_step_C1")
-    seed = int(g["seed"])
-    model = IDRNetwork(idr_conf("C1"))
-    L = P.CONFIGS["C1"][0]
-    levels, B, _, _ = P.make_embedder_state(seed, "C1", 0.05)
-    load_embedder(model.implicit_network.embed_model.embedder_obj, levels, B)
-    sd = model.implicit_network.state_dict()
-    for k, v in P.make_sdf_params(seed + 7, 3 + 4 * L, (512,) * 8, 257, (4,), 0.6, 0.1, 0.1).items():
-        sd[k] = torch.from_numpy(v)
-    model.implicit_network.load_state_dict(sd)
-    vl, vB, _, _ = P.make_embedder_state(seed + 20, "viewdir", 0.5)
-    load_embedder(model.rendering_network.embed_model.embedder_obj, vl, vB)
-    sd = model.rendering_network.state_dict()
-    for k, v in P.make_render_params(seed + 9).items():
-        sd[k] = torch.from_numpy(v)
-    model.rendering_network.load_state_dict(sd)
-    ref = R.RefIDR(model.cpu())
+    g = golden(f"idr_step_{cfg}")
+    model = make_idr(cfg, int(g["seed"]), float(g["bias"]) if "bias" in g.files else 0.6, device="cpu")
+    ref = R.RefIDR(model)
     ref.train()
     inp = {k: torch.from_numpy(g[k]) for k in ("intrinsics", "uv", "pose", "object_mask")}
+    torch.set_num_threads(8)
     torch.manual_seed(1000)
     out = ref(inp)
     lo = IDRLoss(eikonal_weight=0.1, mask_weight=100.0, alpha=50.0)(out, {"rgb": torch.from_numpy(g["rgb_gt"])})
