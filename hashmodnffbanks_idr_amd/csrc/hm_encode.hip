@@ -38,6 +38,22 @@ __device__ __forceinline__ float dpp_add_half_mirror(float v) {
     return v + __int_as_float(t);
 }
 
+// Output-tile store with a cache policy (flags bits 0-1): 0 plain, 1 write-through `sc1` (the line is DROPPED from the
+// XCD's L2 once written: 1.1 GB of output rows per launch no longer push table lines out of the 4 MB L2s), 2 `nt`,
+// 3 `sc0 sc1`.  dst / n_vec describe ONE tile (wave-uniform), i is the lane's float4 index inside it.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_tile_vec(float *dst, unsigned tile_bytes, int i, const float4 &v, int mode) {
+    if (mode == 0) {
+        reinterpret_cast<float4 *>(dst)[i] = v;
+        return;
+    }
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(dst, 0, tile_bytes, 0x00020000);
+    const u32x4 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    if (mode == 1) __builtin_amdgcn_raw_buffer_store_b128(u, rsrc, i * 16, 0, 16);        // sc1
+    else if (mode == 2) __builtin_amdgcn_raw_buffer_store_b128(u, rsrc, i * 16, 0, 2);    // nt
+    else __builtin_amdgcn_raw_buffer_store_b128(u, rsrc, i * 16, 0, 17);                  // sc0 sc1
+}
+
 // corner weight for one axis: reference mode => (bit ? xf : 1-xf) with xf == 0
 template <int FRAC>
 __device__ __forceinline__ void voxel_and_weight(float x, int32_t res, int bit, uint32_t &u, float &w) {
@@ -59,7 +75,8 @@ template <int FRAC>
 __global__ __launch_bounds__(kThreads) void encode_fwd_f2_kernel(HmLevels lv, const float *__restrict__ x, int64_t n,
                                                                  const float2 *__restrict__ table,
                                                                  const float *__restrict__ Bf,
-                                                                 float *__restrict__ out, int64_t out_stride) {
+                                                                 float *__restrict__ out, int64_t out_stride,
+                                                                 int flags) {
     extern __shared__ __align__(16) float smem[];
     const int L = lv.L;
     const bool fourier = (Bf != nullptr);
@@ -149,8 +166,7 @@ __global__ __launch_bounds__(kThreads) void encode_fwd_f2_kernel(HmLevels lv, co
         const int total = cnt * E;
         const int nvec = total >> 2;
         const float4 *s4 = reinterpret_cast<const float4 *>(s_out);
-        float4 *d4 = reinterpret_cast<float4 *>(dst);
-        for (int i = tid; i < nvec; i += kThreads) d4[i] = s4[i];
+        for (int i = tid; i < nvec; i += kThreads) store_tile_vec(dst, (unsigned)total * 4u, i, s4[i], flags & 3);
         for (int i = (nvec << 2) + tid; i < total; i += kThreads) dst[i] = s_out[i];
     } else {
         for (int i = tid; i < cnt * E; i += kThreads) {
@@ -173,11 +189,12 @@ __global__ __launch_bounds__(kThreads) void encode_fwd_f2_kernel(HmLevels lv, co
 constexpr int kTileS = 256, kThreadsS = 512;   // two workgroups per CU: one gathers while the other stores
                                                // (one of 512 points: 4.53 TB/s, two of 256: 4.65, four of 128: 4.45)   // two workgroups per CU: one gathers while the other stores
 
-template <int FRAC>
+template <int FRAC, int KL>   // KL = levels gathered per sweep step (2: one (coarse, fine) pair; 4: more loads in flight)
 __global__ __launch_bounds__(kThreadsS) void encode_fwd_f2_sweep_kernel(HmLevels lv, const float *__restrict__ x,
                                                                         int64_t n, const float2 *__restrict__ table,
                                                                         const float *__restrict__ Bf,
-                                                                        float *__restrict__ out, int64_t out_stride) {
+                                                                        float *__restrict__ out, int64_t out_stride,
+                                                                        int flags) {
     extern __shared__ __align__(16) float smem[];
     const int L = lv.L;
     const bool fourier = (Bf != nullptr);
@@ -190,13 +207,17 @@ __global__ __launch_bounds__(kThreadsS) void encode_fwd_f2_sweep_kernel(HmLevels
     const int corner = lane & 7, sub = lane >> 3;
     const int bx = corner & 1, by = (corner >> 1) & 1, bz = (corner >> 2) & 1;
     const int64_t n_tiles = (n + kTileS - 1) / kTileS;
-    const int half = (L + 1) / 2;
+    const int half = (L + KL - 1) / KL;
 
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t base = tile * kTileS;
         const int cnt = (int)min((int64_t)kTileS, n - base);
         __syncthreads();   // the previous tile's rows have left s_out
-        for (int i = tid; i < kTileS * 3; i += kThreadsS) s_x[i] = (i < cnt * 3) ? x[base * 3 + i] : 0.0f;
+        if (flags & 4)
+            for (int i = tid; i < kTileS * 3; i += kThreadsS)
+                s_x[i] = (i < cnt * 3) ? __builtin_nontemporal_load(x + base * 3 + i) : 0.0f;
+        else
+            for (int i = tid; i < kTileS * 3; i += kThreadsS) s_x[i] = (i < cnt * 3) ? x[base * 3 + i] : 0.0f;
         __syncthreads();
         if (fourier) {
             const int p = tid & (kTileS - 1);
@@ -221,11 +242,13 @@ __global__ __launch_bounds__(kThreadsS) void encode_fwd_f2_sweep_kernel(HmLevels
         // wave w owns points [32w, 32w+32) of the tile: 4 passes of 8 points x 8 corners, two levels per sweep step
         // (gathering step lp+1 while step lp is reduced - two register sets - measured 2-7 % SLOWER)
         for (int lp = 0; lp < half; ++lp) {
-            const int lvl[2] = {lp, lp + half};
-            float2 v[2][4];
-            float w[2][4];
+            int lvl[KL];
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < KL; ++k) lvl[k] = lp + k * half;
+            float2 v[KL][4];
+            float w[KL][4];
+#pragma unroll
+            for (int k = 0; k < KL; ++k) {
                 const int l = min(lvl[k], L - 1);
                 const int32_t res = lv.res[l];
                 const uint32_t rows = lv.rows[l], magic = lv.magic[l];
@@ -243,7 +266,7 @@ __global__ __launch_bounds__(kThreadsS) void encode_fwd_f2_sweep_kernel(HmLevels
                 }
             }
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < KL; ++k) {
                 if (lvl[k] >= L) continue;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -266,8 +289,7 @@ __global__ __launch_bounds__(kThreadsS) void encode_fwd_f2_sweep_kernel(HmLevels
             const int total = cnt * E;
             const int nvec = total >> 2;
             const float4 *s4 = reinterpret_cast<const float4 *>(s_out);
-            float4 *d4 = reinterpret_cast<float4 *>(dst);
-            for (int i = tid; i < nvec; i += kThreadsS) d4[i] = s4[i];
+            for (int i = tid; i < nvec; i += kThreadsS) store_tile_vec(dst, (unsigned)total * 4u, i, s4[i], flags & 3);
             for (int i = (nvec << 2) + tid; i < total; i += kThreadsS) dst[i] = s_out[i];
         } else {
             for (int i = tid; i < cnt * E; i += kThreadsS) {
@@ -404,30 +426,35 @@ int hm_encode_fwd(const hm_grid_desc *desc, const float *x, int64_t n, const flo
     if (n == 0) return HM_OK;
     HM_CHECK_ARG(x && table && out, "hm_encode_fwd: NULL pointer");
     static const int sweep_cfg = [] { const char *e = getenv("HM_ENCODE_SWEEP"); return e ? atoi(e) : 1; }();
+    // cache policy of the output-row stores / x loads (see store_tile_vec); HM_ENCODE_FLAGS overrides for experiments
+    static const int enc_flags = [] { const char *e = getenv("HM_ENCODE_FLAGS"); return e ? atoi(e) : 0; }();
+    static const int sweep_grid = [] { const char *e = getenv("HM_ENCODE_GRID"); return e ? atoi(e) : 512; }();
     const size_t lds_sweep = sizeof(float) * (size_t)(kTileS * width + kTileS * 3);
     const bool table_exceeds_l2 = desc->total_rows * (uint64_t)lv.F * 4u > (8u << 20);   // (C1's 0.9 MiB: tile kernel)
     if (lv.F == 2 && sweep_cfg != 0 && table_exceeds_l2 && n >= (int64_t)131072 && lds_sweep <= 160 * 1024) {
         // big launches over big tables: level-synchronous persistent kernel (two workgroups per CU)
         static thread_local bool attr_done = false;
         if (!attr_done) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_fwd_f2_sweep_kernel<HM_FRAC_REFERENCE>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e == hipSuccess)
-                e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_fwd_f2_sweep_kernel<HM_FRAC_TRILINEAR>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipError_t e = hipSuccess;
+            const void *fns[4] = {reinterpret_cast<const void *>(encode_fwd_f2_sweep_kernel<HM_FRAC_REFERENCE, 2>),
+                                  reinterpret_cast<const void *>(encode_fwd_f2_sweep_kernel<HM_FRAC_TRILINEAR, 2>),
+                                  reinterpret_cast<const void *>(encode_fwd_f2_sweep_kernel<HM_FRAC_REFERENCE, 4>),
+                                  reinterpret_cast<const void *>(encode_fwd_f2_sweep_kernel<HM_FRAC_TRILINEAR, 4>)};
+            for (int i = 0; i < 4 && e == hipSuccess; ++i)
+                e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return hm_fail(HM_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
             attr_done = true;
         }
         const int64_t tiles = (n + kTileS - 1) / kTileS;
-        const unsigned grid = (unsigned)(tiles < 512 ? tiles : 512);
-        if (frac_mode == HM_FRAC_REFERENCE)
-            hipLaunchKernelGGL(encode_fwd_f2_sweep_kernel<HM_FRAC_REFERENCE>, dim3(grid), dim3(kThreadsS), lds_sweep,
-                               as_stream(stream), lv, x, n, reinterpret_cast<const float2 *>(table), B_fourier, out,
-                               out_stride);
-        else
-            hipLaunchKernelGGL(encode_fwd_f2_sweep_kernel<HM_FRAC_TRILINEAR>, dim3(grid), dim3(kThreadsS), lds_sweep,
-                               as_stream(stream), lv, x, n, reinterpret_cast<const float2 *>(table), B_fourier, out,
-                               out_stride);
+        const unsigned grid = (unsigned)(tiles < sweep_grid ? tiles : sweep_grid);
+        const bool kl4 = (enc_flags & 8) != 0;
+#define HM_SWEEP_LAUNCH(FR, KLV)                                                                                    \
+    hipLaunchKernelGGL((encode_fwd_f2_sweep_kernel<FR, KLV>), dim3(grid), dim3(kThreadsS), lds_sweep,               \
+                       as_stream(stream), lv, x, n, reinterpret_cast<const float2 *>(table), B_fourier, out,        \
+                       out_stride, enc_flags)
+        if (frac_mode == HM_FRAC_REFERENCE) { if (kl4) HM_SWEEP_LAUNCH(HM_FRAC_REFERENCE, 4); else HM_SWEEP_LAUNCH(HM_FRAC_REFERENCE, 2); }
+        else { if (kl4) HM_SWEEP_LAUNCH(HM_FRAC_TRILINEAR, 4); else HM_SWEEP_LAUNCH(HM_FRAC_TRILINEAR, 2); }
+#undef HM_SWEEP_LAUNCH
     } else if (lv.F == 2) {
         const int64_t tiles = (n + kTile - 1) / kTile;
         HM_CHECK_ARG(tiles <= 0x7fffffffLL, "hm_encode_fwd: n too large for one launch");
@@ -435,11 +462,11 @@ int hm_encode_fwd(const hm_grid_desc *desc, const float *x, int64_t n, const flo
         if (frac_mode == HM_FRAC_REFERENCE)
             hipLaunchKernelGGL(encode_fwd_f2_kernel<HM_FRAC_REFERENCE>, dim3((unsigned)tiles), dim3(kThreads), lds,
                                as_stream(stream), lv, x, n, reinterpret_cast<const float2 *>(table), B_fourier, out,
-                               out_stride);
+                               out_stride, enc_flags);
         else
             hipLaunchKernelGGL(encode_fwd_f2_kernel<HM_FRAC_TRILINEAR>, dim3((unsigned)tiles), dim3(kThreads), lds,
                                as_stream(stream), lv, x, n, reinterpret_cast<const float2 *>(table), B_fourier, out,
-                               out_stride);
+                               out_stride, enc_flags);
     } else {
         const int64_t threads = n * (lv.L + 1);
         const int64_t grid = (threads + kThreads - 1) / kThreads;

@@ -23,6 +23,7 @@
 #include "hm_common.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -293,6 +294,233 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_kernel(HmLevels lv, Sd
             for (int i = tid; i < cnt * od; i += kThreadsSdf) {
                 const int p = i / od, f = i - p * od;
                 float v = X[(f >> 2) * kGroupFloats + p * 4 + (f & 3)];
+                if (f == 0) v = sdf_clamp(v, net.beta);
+                out[(base + p) * out_stride + f] = v;
+            }
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// 32-point tiles, TWO workgroups per CU (4 waves each, 74 KB of LDS each) - the throughput variant for big batches.
+// One 64-point workgroup per CU leaves the matrix pipes idle whenever all of its waves sit in a layer's epilogue,
+// at one of the two barriers per layer, in the encode phase or in the last layer's VALU dot (23 % of the tile time,
+// 121 of 157 TFLOP/s).  Two independent workgroups drift out of phase and fill each other's bubbles; the price is the
+// weight stream per CU (two tiles x 7.9 MB per ~410 us = 39 GB/s, well under the ~85 GB/s a CU draws from L2).
+// Wave w owns feature tiles 4w .. 4w+3 (128 features) for all 32 points: per k octet 4 coalesced 1-KB A loads, one
+// ds_read_b128 of B and 16 MFMAs - the same arithmetic intensity per LDS byte as the 64-point kernel.
+constexpr int kPts32 = 32;
+constexpr int kThreads32 = 256;
+constexpr int kWaves32 = 4;
+constexpr int kGroupFloats32 = kPts32 * 4;
+
+template <int FRAC>
+__global__ __launch_bounds__(kThreads32, 2) void sdf_fwd_p32_kernel(HmLevels lv, SdfNet net,
+                                                                     const float *__restrict__ x, int64_t n,
+                                                                     const float *__restrict__ table,
+                                                                     const float *__restrict__ Bf,
+                                                                     float *__restrict__ out, int64_t out_stride,
+                                                                     int out_cols, const int32_t *__restrict__ n_dev,
+                                                                     int64_t run_min, int64_t run_max) {
+    extern __shared__ __align__(16) float lds[];
+    if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));
+    if (n < run_min || n > run_max) return;
+    float *X = lds;
+    float *EMB = lds + (size_t)net.x_groups * kGroupFloats32;
+    float *SX = EMB + (size_t)net.emb_groups * kGroupFloats32;  // [32][3] raw points (+ pad)
+    float *RED = SX + kPts32 * 4;                                // [8][32] partial sums of the sdf-only last layer
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    const int j = lane & 31;  // point / feature row within a 32-feature tile
+    const int h = lane >> 5;
+    const int L = lv.L, F = lv.F;
+    const int E = lv.E;
+    const int64_t n_tiles = (n + kPts32 - 1) / kPts32;
+
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t base = tile * kPts32;
+        const int cnt = (int)min((int64_t)kPts32, n - base);
+        __syncthreads();
+        if (tid < kPts32 * 3) SX[tid] = (tid < cnt * 3) ? x[base * 3 + tid] : 0.0f;
+        __syncthreads();
+
+        // ---------------- encode -> EMB[(e/4)][p][e%4]: thread -> (point p, slot grp of 8) ----------------
+        {
+            const int p = tid & (kPts32 - 1);
+            const int grp = tid >> 5;  // 0..7
+            const float x0 = SX[p * 3], x1 = SX[p * 3 + 1], x2 = SX[p * 3 + 2];
+            auto put = [&](int e, float v) { EMB[(e >> 2) * kGroupFloats32 + p * 4 + (e & 3)] = v; };
+            if (grp == 0) {
+                put(0, x0); put(1, x1); put(2, x2);
+                for (int e = E; e < net.emb_groups * 4; ++e) put(e, 0.0f);
+            }
+            const float two_pi = 6.283185307179586f;
+            const float s0 = __fmul_rn(two_pi, x0), s1 = __fmul_rn(two_pi, x1), s2 = __fmul_rn(two_pi, x2);
+            for (int c = grp; c < L; c += 8) {
+                float a = __fmul_rn(s0, Bf[c]);
+                a = __fmaf_rn(s1, Bf[L + c], a);
+                a = __fmaf_rn(s2, Bf[2 * L + c], a);
+                float sn, cs;
+                sincosf(a, &sn, &cs);
+                put(3 + c, sn);
+                put(3 + L + c, cs);
+            }
+            for (int l = grp; l < L; l += 8) {
+                float acc[8];
+                for (int f = 0; f < F; ++f) acc[f] = 0.0f;
+                const float *tl = table + (size_t)lv.row_off[l] * F;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    uint32_t ux, uy, uz;
+                    float wx, wy, wz;
+                    corner<FRAC>(x0, lv.res[l], c & 1, ux, wx);
+                    corner<FRAC>(x1, lv.res[l], (c >> 1) & 1, uy, wy);
+                    corner<FRAC>(x2, lv.res[l], (c >> 2) & 1, uz, wz);
+                    const float w = __fmul_rn(__fmul_rn(wx, wy), wz);
+                    if (w != 0.0f) {
+                        const uint32_t id = hm_mod_rows(hm_hash3(ux, uy, uz), lv.rows[l], lv.magic[l]);
+                        for (int f = 0; f < F; ++f) acc[f] = __fadd_rn(acc[f], __fmul_rn(tl[(size_t)id * F + f], w));
+                    }
+                }
+                for (int f = 0; f < F; ++f) put(3 + 2 * L + l * F + f, acc[f]);
+            }
+        }
+        __syncthreads();
+
+        // ---------------- layers ------------------------------------------------------------
+        for (int li = 0; li < net.n_layers; ++li) {
+            const hm_mlp_layer &Ly = net.layer[li];
+            const int n_oct = Ly.seg_octets[0] + Ly.seg_octets[1];
+            if (li == net.n_layers - 1 && out_cols == 1) {
+                // sdf-only last layer: VALU dot product; lane (point j, half h) of wave w walks k-groups 2w + h (mod 8)
+                const float4 *W0 = reinterpret_cast<const float4 *>(Ly.w_packed);
+                float part = 0.0f;
+                int kg0 = 0;
+                for (int seg = 0; seg < 2; ++seg) {
+                    const float *src = (Ly.seg_src[seg] == 0) ? X : EMB;
+                    const int ng = 2 * Ly.seg_octets[seg];
+                    for (int kg = 2 * wave + h; kg < ng; kg += 2 * kWaves32) {
+                        const float4 xv = *reinterpret_cast<const float4 *>(src + kg * kGroupFloats32 + j * 4);
+                        const int kk = kg0 + kg;
+                        const float4 wv = W0[(size_t)(kk >> 1) * 64 + 32 * (kk & 1)];
+                        part = __fmaf_rn(xv.x, wv.x, part);
+                        part = __fmaf_rn(xv.y, wv.y, part);
+                        part = __fmaf_rn(xv.z, wv.z, part);
+                        part = __fmaf_rn(xv.w, wv.w, part);
+                    }
+                    kg0 += ng;
+                }
+                RED[(2 * wave + h) * kPts32 + j] = part;
+                __syncthreads();
+                if (tid < cnt) {
+                    float sacc = Ly.bias[0];
+                    for (int w8 = 0; w8 < 2 * kWaves32; ++w8) sacc += RED[w8 * kPts32 + tid];
+                    out[(base + tid) * out_stride] = sdf_clamp(sacc, net.beta);
+                }
+                break;
+            }
+            const int nt = Ly.n_tiles;
+            const int t0 = 4 * wave;
+            const int ntw = max(0, min(4, nt - t0));
+            f32x16 acc0 = {0}, acc1 = {0}, acc2 = {0}, acc3 = {0};
+            if (ntw > 0) {
+                const float4 *A0 = reinterpret_cast<const float4 *>(Ly.w_packed) + ((size_t)t0 * n_oct) * 64 + lane;
+                const size_t ts = (size_t)n_oct * 64;
+                const float4 *A1 = A0 + (ntw > 1 ? ts : 0);
+                const float4 *A2 = A0 + (ntw > 2 ? 2 * ts : 0);
+                const float4 *A3 = A0 + (ntw > 3 ? 3 * ts : 0);
+                const int no0 = Ly.seg_octets[0];
+                const float *src0 = (Ly.seg_src[0] == 0) ? X : EMB;
+                const float *src1 = (Ly.seg_src[1] == 0) ? X : EMB;
+                float4 r0[4], r1[4], r2[4], r3[4];
+#pragma unroll
+                for (int st = 0; st < 3; ++st) {
+                    const size_t off = (size_t)min(st, n_oct - 1) * 64;
+                    r0[st] = A0[off]; r1[st] = A1[off]; r2[st] = A2[off]; r3[st] = A3[off];
+                }
+                auto octet = [&](int gg, const float4 &a0, const float4 &a1, const float4 &a2, const float4 &a3) {
+                    const float *src = (gg < no0) ? src0 + (2 * gg + h) * kGroupFloats32
+                                                  : src1 + (2 * (gg - no0) + h) * kGroupFloats32;
+                    const float4 b = *reinterpret_cast<const float4 *>(src + j * 4);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b.x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b.x, acc1, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.x, b.x, acc2, 0, 0, 0);
+                    acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a3.x, b.x, acc3, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b.y, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b.y, acc1, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.y, b.y, acc2, 0, 0, 0);
+                    acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a3.y, b.y, acc3, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b.z, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b.z, acc1, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.z, b.z, acc2, 0, 0, 0);
+                    acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a3.z, b.z, acc3, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b.w, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b.w, acc1, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.w, b.w, acc2, 0, 0, 0);
+                    acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a3.w, b.w, acc3, 0, 0, 0);
+                };
+                // (whole groups of four octets without an exit test: see the 64-point kernel)
+                const int n_full = n_oct & ~3;
+                for (int gg0 = 0; gg0 < n_full; gg0 += 4) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int gg = gg0 + u;
+                        {
+                            const size_t off = (size_t)min(gg + 3, n_oct - 1) * 64;
+                            r0[(u + 3) & 3] = A0[off]; r1[(u + 3) & 3] = A1[off];
+                            r2[(u + 3) & 3] = A2[off]; r3[(u + 3) & 3] = A3[off];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        octet(gg, r0[u], r1[u], r2[u], r3[u]);
+                    }
+                }
+                if (n_full + 0 < n_oct) octet(n_full + 0, r0[0], r1[0], r2[0], r3[0]);
+                if (n_full + 1 < n_oct) octet(n_full + 1, r0[1], r1[1], r2[1], r3[1]);
+                if (n_full + 2 < n_oct) octet(n_full + 2, r0[2], r1[2], r2[2], r3[2]);
+            }
+            __syncthreads();  // every wave has finished reading X / EMB for this layer
+
+            const bool act = Ly.activation != 0;
+            const bool div = Ly.post_div_sqrt2 != 0;
+            const float sqrt2 = 1.41421356237309515f;
+            auto store_tile = [&](const f32x16 &acc, int ft) {
+                const int fbase = 32 * (t0 + ft);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int f = fbase + 8 * q + 4 * h;
+                    const float4 bb = *reinterpret_cast<const float4 *>(Ly.bias + f);
+                    float v0 = acc[4 * q + 0] + bb.x, v1 = acc[4 * q + 1] + bb.y, v2 = acc[4 * q + 2] + bb.z,
+                          v3 = acc[4 * q + 3] + bb.w;
+                    if (act) {
+                        v0 = softplus100(v0); v1 = softplus100(v1); v2 = softplus100(v2); v3 = softplus100(v3);
+                    }
+                    if (div) {
+                        v0 = __fdiv_rn(v0, sqrt2); v1 = __fdiv_rn(v1, sqrt2); v2 = __fdiv_rn(v2, sqrt2);
+                        v3 = __fdiv_rn(v3, sqrt2);
+                    }
+                    *reinterpret_cast<float4 *>(X + (f >> 2) * kGroupFloats32 + j * 4) = make_float4(v0, v1, v2, v3);
+                }
+            };
+            if (ntw > 0) store_tile(acc0, 0);
+            if (ntw > 1) store_tile(acc1, 1);
+            if (ntw > 2) store_tile(acc2, 2);
+            if (ntw > 3) store_tile(acc3, 3);
+            if (li == 0 && net.emb_groups > 0) {
+                for (int i = tid; i < net.emb_groups * kGroupFloats32; i += kThreads32)
+                    EMB[i] = __fdiv_rn(EMB[i], sqrt2);
+            }
+            __syncthreads();
+        }
+
+        const hm_mlp_layer &last = net.layer[net.n_layers - 1];
+        if (out_cols != 1) {
+            const int od = last.out_dim;
+            for (int i = tid; i < cnt * od; i += kThreads32) {
+                const int p = i / od, f = i - p * od;
+                float v = X[(f >> 2) * kGroupFloats32 + p * 4 + (f & 3)];
                 if (f == 0) v = sdf_clamp(v, net.beta);
                 out[(base + p) * out_stride + f] = v;
             }
@@ -832,8 +1060,9 @@ int hm_sdf_fwd(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *x,
     HM_CHECK_ARG(n >= 0, "hm_sdf_fwd: n < 0");
     HM_CHECK_ARG(frac_mode == HM_FRAC_REFERENCE || frac_mode == HM_FRAC_TRILINEAR, "hm_sdf_fwd: bad frac_mode");
     HM_CHECK_ARG(mlp->n_layers >= 1 && mlp->n_layers <= HM_MAX_LAYERS, "hm_sdf_fwd: n_layers out of range");
-    HM_CHECK_ARG(tile_points == 0 || tile_points == 4 || tile_points == 8 || tile_points == 16 || tile_points == 64,
-                 "hm_sdf_fwd: tile_points must be 0, 4, 8, 16 or 64");
+    HM_CHECK_ARG(tile_points == 0 || tile_points == 4 || tile_points == 8 || tile_points == 16 || tile_points == 32 ||
+                     tile_points == 64,
+                 "hm_sdf_fwd: tile_points must be 0, 4, 8, 16, 32 or 64");
     const HmLevels &lv = desc->lv;
     SdfNet net;
     net.n_layers = mlp->n_layers;
@@ -892,7 +1121,7 @@ int hm_sdf_fwd(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *x,
     if (tile_points == 8) { run16 = true; m8_max = kBig; }
     else if (tile_points == 4) { run16 = true; m8_max = kBig; m4_max = kBig; }
     else if (tile_points == 16) run16 = true;
-    else if (tile_points == 64 || !have16) run64 = true;
+    else if (tile_points == 64 || tile_points == 32 || !have16) run64 = true;
     else if (!n_dev) { run16 = n <= kSmall; run64 = !run16; m8_max = kTiny; m4_max = kMini; }
     else if (n <= kSmall) { run16 = true; m8_max = kTiny; m4_max = kMini; }
     else { run16 = run64 = true; hi16 = kSmall; lo64 = kSmall + 1; m8_max = kTiny; m4_max = kMini; }
@@ -930,6 +1159,34 @@ int hm_sdf_fwd(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *x,
             hipLaunchKernelGGL(sdf_fwd_small_kernel<HM_FRAC_TRILINEAR>, dim3((unsigned)grid), dim3(kThreadsSdf), lds,
                                as_stream(stream), lv, net, x, n, table, B_fourier, out, out_stride, out_cols, n_dev,
                                lo16, hi16, m8_max, m4_max);
+    }
+    // big batches: two 32-point workgroups per CU (default) or one 64-point workgroup (HM_SDF_P32=0)
+    static const int use_p32 = [] { const char *e = getenv("HM_SDF_P32"); return e ? atoi(e) : 1; }();
+    const size_t lds32 = sizeof(float) * ((size_t)(net.x_groups + net.emb_groups) * kGroupFloats32 + kPts32 * 4 +
+                                          2 * kWaves32 * kPts32);
+    if (run64 && (use_p32 || tile_points == 32) && tile_points != 64 && lds32 <= 80 * 1024) {
+        static thread_local bool attr32_done = false;
+        if (!attr32_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sdf_fwd_p32_kernel<HM_FRAC_REFERENCE>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(sdf_fwd_p32_kernel<HM_FRAC_TRILINEAR>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            if (e != hipSuccess) return hm_fail(HM_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+            attr32_done = true;
+        }
+        const int64_t tiles = (n + kPts32 - 1) / kPts32;
+        const int64_t cap = max_workgroups > 0 ? max_workgroups : 512;   // two resident workgroups per CU
+        const int64_t grid = tiles < cap ? tiles : cap;
+        if (frac_mode == HM_FRAC_REFERENCE)
+            hipLaunchKernelGGL(sdf_fwd_p32_kernel<HM_FRAC_REFERENCE>, dim3((unsigned)grid), dim3(kThreads32), lds32,
+                               as_stream(stream), lv, net, x, n, table, B_fourier, out, out_stride, out_cols, n_dev,
+                               lo64, hi64);
+        else
+            hipLaunchKernelGGL(sdf_fwd_p32_kernel<HM_FRAC_TRILINEAR>, dim3((unsigned)grid), dim3(kThreads32), lds32,
+                               as_stream(stream), lv, net, x, n, table, B_fourier, out, out_stride, out_cols, n_dev,
+                               lo64, hi64);
+        run64 = false;
     }
     if (run64) {
         const size_t lds = sizeof(float) * ((size_t)(net.x_groups + net.emb_groups) * kGroupFloats + kPts * 4 +

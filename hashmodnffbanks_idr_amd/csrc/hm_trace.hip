@@ -29,6 +29,7 @@ enum : int32_t {  // counters (device int32 array)
     C_ANY_LIVE = 69,     // some ray was still marching after the first evaluation (=> >= 1 global iteration)
     C_EVALS = 70,        // total SDF point evaluations (statistics)
     C_UNFINISHED = 71,   // rays whose state machine had not finished after the last march round
+    C_BIG_PTS = 73,      // points of the one big SDF launch: sampler points followed by closest-approach points
     C_NONFINITE = 72,    // SDF values consumed by the search that were NaN / Inf (must be 0: a NaN fails every
                          // `sdf > threshold` test, so the ray would silently count as converged where it stands)
     C_COUNT = 80
@@ -196,13 +197,19 @@ __global__ __launch_bounds__(kTB) void trace_finalize_kernel(TraceArgs a) {
 }
 
 // n_steps samples along every listed ray: t = lo + f*(hi - lo)  (ray_tracing.py:198-206, 277-286)
+// c_base >= 0: the points are appended behind the cnt[c_base] points already in the buffer (one SDF launch then
+// evaluates both sets); cnt[C_BIG_PTS] receives the total.
 __global__ __launch_bounds__(kTB) void ray_samples_kernel(TraceArgs a, const int32_t *list, int c_n, int c_npts,
                                                           const float *lo_arr, const float *hi_arr,
-                                                          const float *fr) {
+                                                          const float *fr, int c_base) {
     const int64_t gid = (int64_t)blockIdx.x * kTB + threadIdx.x;
     const TraceWs &w = a.w;
     const int32_t n_list = w.cnt[c_n];
-    if (gid == 0) w.cnt[c_npts] = n_list * a.n_steps;
+    const int64_t base = c_base >= 0 ? w.cnt[c_base] : 0;
+    if (gid == 0) {
+        w.cnt[c_npts] = n_list * a.n_steps;
+        w.cnt[C_BIG_PTS] = (int32_t)base + n_list * a.n_steps;
+    }
     const int64_t m = gid / a.n_steps;
     if (m >= n_list) return;
     const int s = (int)(gid - m * a.n_steps);
@@ -211,7 +218,8 @@ __global__ __launch_bounds__(kTB) void ray_samples_kernel(TraceArgs a, const int
     const float t = __fadd_rn(lo, __fmul_rn(fr[s], __fsub_rn(hi, lo)));
     float px, py, pz;
     along(a, i, t, px, py, pz);
-    w.pts[gid * 3] = px; w.pts[gid * 3 + 1] = py; w.pts[gid * 3 + 2] = pz;
+    const int64_t o = base + gid;
+    w.pts[o * 3] = px; w.pts[o * 3 + 1] = py; w.pts[o * 3 + 2] = pz;
 }
 
 __device__ __forceinline__ float secant_z(float v_lo, float v_hi, float z_lo, float z_hi) {
@@ -333,7 +341,7 @@ __global__ __launch_bounds__(kTB) void closest_reduce_kernel(TraceArgs a) {
     if (m >= w.cnt[C_NSEL]) return;
     const int64_t i = w.list_sel[m];
     const int n = a.n_steps;
-    const float *v = w.vals + m * n;
+    const float *v = w.vals + (int64_t)w.cnt[C_NSAMP_PTS] + m * n;   // behind the sampler's values (one launch)
     int amin = 0, bad = !isfinite(v[0]);
     float best = v[0];
     for (int s = 1; s < n; ++s) {
@@ -457,13 +465,21 @@ int hm_trace_forward(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const flo
     }
     hipLaunchKernelGGL(trace_finalize_kernel, dim3(g_rays), dim3(kTB), 0, st, a);
 
-    // ---- 2. sampler + secant for rays that did not converge ----------------------------------------
+    // ---- 2. sampler + (training) closest approach: ONE SDF launch over both point sets ----------------------
+    // The mask-loss rays (ray_tracing.py:71-92) are exactly the rays the sampler does NOT touch, so their
+    // n_steps random-fraction samples do not depend on the sampler's outcome: they are appended behind the
+    // sampler's points and evaluated by the same launch (one dependent launch and one partial last wave less).
+    if (cfg->training) hipLaunchKernelGGL(tail_prepare_kernel, dim3(g_rays), dim3(kTB), 0, st, a);
     hipLaunchKernelGGL(ray_samples_kernel, dim3(g_samp), dim3(kTB), 0, st, a, a.w.list_samp, (int)C_NSAMP,
-                       (int)C_NSAMP_PTS, a.w.t_s, a.w.t_e, sampler_fracs);
+                       (int)C_NSAMP_PTS, a.w.t_s, a.w.t_e, sampler_fracs, -1);
+    if (cfg->training)
+        hipLaunchKernelGGL(ray_samples_kernel, dim3(g_samp), dim3(kTB), 0, st, a, a.w.list_sel, (int)C_NSEL,
+                           (int)C_NSEL_PTS, a.w.t_min, a.w.t_max, steps_u, (int)C_NSAMP_PTS);
     {
-        int rc = sdf(n_rays * cfg->n_steps, a.w.cnt + C_NSAMP_PTS);
+        int rc = sdf(n_rays * cfg->n_steps, a.w.cnt + C_BIG_PTS);
         if (rc != HM_OK) return rc;
     }
+    if (cfg->training) hipLaunchKernelGGL(closest_reduce_kernel, dim3(g_rays), dim3(kTB), 0, st, a);
     hipLaunchKernelGGL(sampler_reduce_kernel, dim3(g_rays), dim3(kTB), 0, st, a);
     if (cfg->n_secant_steps > 0) {
         hipLaunchKernelGGL(secant_points_kernel, dim3(g_rays), dim3(kTB), 0, st, a);
@@ -473,16 +489,6 @@ int hm_trace_forward(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const flo
             hipLaunchKernelGGL(secant_advance_kernel, dim3(g_rays), dim3(kTB), 0, st, a,
                                s == cfg->n_secant_steps - 1 ? 1 : 0);
         }
-    }
-
-    // ---- 3. training only: closest approach for the mask-loss rays --------------------------------
-    if (cfg->training) {
-        hipLaunchKernelGGL(tail_prepare_kernel, dim3(g_rays), dim3(kTB), 0, st, a);
-        hipLaunchKernelGGL(ray_samples_kernel, dim3(g_samp), dim3(kTB), 0, st, a, a.w.list_sel, (int)C_NSEL,
-                           (int)C_NSEL_PTS, a.w.t_min, a.w.t_max, steps_u);
-        int rc = sdf(n_rays * cfg->n_steps, a.w.cnt + C_NSEL_PTS);
-        if (rc != HM_OK) return rc;
-        hipLaunchKernelGGL(closest_reduce_kernel, dim3(g_rays), dim3(kTB), 0, st, a);
     }
     hipLaunchKernelGGL(count_evals_kernel, dim3(1), dim3(64), 0, st, a.w.cnt, rounds + 1, cfg->n_secant_steps);
     if (stats_out) {

@@ -141,10 +141,12 @@ class _SdfMlp(torch.autograd.Function):
                                              z=z_list[l], g=v_list[l + 1], out1=dst,
                                              out3=ustack[l][:N] if stacked else None)
                 else:
-                    w0 = Ws[l][0]                                # last layer: u = c * onehot(0)
-                    cb = vb @ w0                                 # c-bar = u-bar[:, 0]
+                    # last layer: u = c * onehot(0).  c-bar = u-bar[:, 0] = v-bar W[0]^T;  W-bar[0] = c^T v-bar
+                    # (both on the library's GEMM: torch.matmul would put a vendor GEMV and, for the row assignment,
+                    #  a MEMCPY node into the captured iteration)
+                    cb = gemm(vb, Ws[l][0:1], None, False, True)             # [N, 1]
                     if need_w[l]:
-                        dW[l][0] = c @ vb
+                        gemm(c.view(N, 1), vb, None, True, False, out=dW[l][0:1], accumulate=True)
 
         # ---- backward of the forward sweep (walks the layers downwards) ------------------------------------
         zb = ops.sdf_head_bwd(d_out, sdf, c, denom, cb)

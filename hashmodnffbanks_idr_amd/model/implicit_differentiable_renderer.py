@@ -430,22 +430,26 @@ class IDRNetwork(nn.Module):
             ray_dirs = ray_dirs.reshape(-1, 3)
             cams = cam_loc.unsqueeze(1).repeat(1, num_pixels, 1).reshape(-1, 3)
 
-            x_all = torch.cat([points.detach(), eikonal_points], 0)
+            # the rows are independent, so the merged evaluation runs in the ORDER grad_theta wants
+            # ([eikonal samples ; ray points], reference :284,:291): no re-ordering copy, and no row / select slicing
+            # of graph tensors (their autograd backward is zeros + a contiguous copy_ = a MEMCPY graph node)
+            n_eik = eikonal_points.shape[0]
+            x_all = torch.cat([eikonal_points, points.detach()], 0)
             out_all, g_all = self.implicit_network.forward_with_gradient(x_all)
-            sdf_output = out_all[:n_rays, 0:1]
+            grad_theta = g_all.reshape(-1, 3)
+            sdf_output = ops.take_block(out_all, n_eik, n_rays, 0, 1)
             surface_mask = network_object_mask & object_mask
             m = surface_mask.unsqueeze(-1)
-            grad_theta = torch.cat([g_all[n_rays:, 0, :], g_all[:n_rays, 0, :]], 0)
 
             # SampleNetwork (sample_network.py:10-20) on every ray; denominators of non-surface rays -> 1
-            grad0 = g_all[:n_rays, 0, :].detach()
+            grad0 = grad_theta.detach()[n_eik:]
             dot = (grad0 * ray_dirs).sum(-1, keepdim=True)
             dot = torch.where(m, dot, torch.ones_like(dot))
             t_theta = dists.unsqueeze(-1) - (sdf_output - sdf_output.detach()) / dot
             diff_points = cams + t_theta * ray_dirs
 
             out2, g2 = self.implicit_network.forward_with_gradient(diff_points)
-            rgb = self.rendering_network(diff_points, g2[:, 0, :], -ray_dirs, out2[:, 1:])
+            rgb = self.rendering_network(diff_points, g2.reshape(-1, 3), -ray_dirs, out2[:, 1:])
             rgb_values = torch.where(m, rgb, torch.ones_like(rgb))
             return {
                 'points': points, 'rgb_values': rgb_values, 'sdf_output': sdf_output,

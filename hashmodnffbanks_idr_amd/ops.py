@@ -492,6 +492,50 @@ def dcopy_(dst, src):
     return dst
 
 
+class _TakeBlock(torch.autograd.Function):
+    """y = x[r0:r0+nr, c0:c0+nc] as a fresh contiguous tensor.  Plain slicing is a view whose autograd backward
+    (SliceBackward: zeros + narrow().copy_()) copies contiguous rows with hipMemcpyAsync, i.e. a MEMCPY node in a
+    captured graph; here both directions are kernel copies (hm_copy2d_f32).  Differentiable to any order."""
+
+    @staticmethod
+    def forward(ctx, x, r0, nr, c0, nc):
+        ctx.box = (x.shape, r0, nr, c0, nc)
+        y = torch.empty((nr, nc), dtype=torch.float32, device=x.device)
+        return dcopy_(y, x[r0:r0 + nr, c0:c0 + nc])
+
+    @staticmethod
+    def backward(ctx, dy):
+        shape, r0, nr, c0, nc = ctx.box
+        return _PutBlock.apply(dy, shape, r0, nr, c0, nc), None, None, None, None
+
+
+class _PutBlock(torch.autograd.Function):
+    """zeros(shape) with dy written at [r0:r0+nr, c0:c0+nc] (the adjoint of _TakeBlock)."""
+
+    @staticmethod
+    def forward(ctx, dy, shape, r0, nr, c0, nc):
+        ctx.box = (r0, nr, c0, nc)
+        dx = torch.zeros(shape, dtype=torch.float32, device=dy.device)      # fill kernel
+        dcopy_(dx[r0:r0 + nr, c0:c0 + nc], dy if dy.stride(-1) == 1 else dy.contiguous())
+        return dx
+
+    @staticmethod
+    def backward(ctx, ddx):
+        r0, nr, c0, nc = ctx.box
+        return _TakeBlock.apply(ddx, r0, nr, c0, nc), None, None, None, None, None
+
+
+def take_block(x, r0, nr, c0=0, nc=None):
+    """x[r0:r0+nr, c0:c0+nc] of a 2-D fp32 tensor as a new tensor, with kernel copies in forward and backward."""
+    require_gpu(x)
+    if x.dim() != 2 or x.dtype != torch.float32:
+        raise ValueError("hashmod take_block: 2-D fp32 tensor expected")
+    if x.stride(-1) != 1:
+        x = x.contiguous()
+    nc = x.shape[1] - c0 if nc is None else nc
+    return _TakeBlock.apply(x, int(r0), int(nr), int(c0), int(nc))
+
+
 def cat_rows_(dst, parts, dim):
     """torch.cat(parts, dim, out=dst) for 2-D fp32 tensors through dcopy_ (no MEMCPY graph nodes)."""
     o = 0

@@ -137,8 +137,8 @@ HM_API int hm_pack_mlp_layer(const float *W, int64_t ldw, const float *bias, int
 
 /* x [n,3] -> out.  out_cols == 1: only the clamped sdf, out[i*out_stride];  out_cols == last
  * layer's out_dim: the whole [sdf | feature vector] row.
- * tile_points: 64 (one workgroup per CU, throughput), 16 (small batches), 8 or 4 (<= 2048 / 1024 points: bound by the
- * weight stream alone), 0 = choose by n (on the device when n_dev is given).
+ * tile_points: 32 (two 4-wave workgroups per CU: throughput), 64 (one 8-wave workgroup per CU), 16 (small batches),
+ * 8 or 4 (<= 2048 / 1024 points: bound by the weight stream alone), 0 = choose by n (on the device when n_dev is given).
  * n_dev: optional DEVICE int32; when non-NULL the kernel evaluates min(n, *n_dev) points, so a
  *        caller that compacts work on the device needs no host synchronisation (n is the capacity).
  * max_workgroups <= 0: fill the chip once (persistent grid-stride over tiles).                    */

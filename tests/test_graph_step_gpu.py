@@ -106,12 +106,13 @@ def test_graph_contains_no_memset_or_memcpy_nodes_of_ours(tmp_path):
     nodes = re.findall(r'"(graph_\d+_node_\d+)"\[[^\]]*?label="\{\s*\n?(\w+)\n([^"]*)"', dot)
     def short(body):
         m = re.search(r"\| (_Z\w+)", body)
-        return m.group(1)[:90] if m else re.sub(r"\s+", " ", body)[:160]
+        return m.group(1)[:260] if m else re.sub(r"\s+", " ", body)[:400]
     copies = [i for i, n in enumerate(nodes) if n[1] != "KERNEL"]
     for i in copies:
         print(f"non-kernel node {nodes[i][1]}: {short(nodes[i][2])}")
-        print(f"    after  {short(nodes[i - 1][2]) if i else '-'}")
-        print(f"    before {short(nodes[i + 1][2]) if i + 1 < len(nodes) else '-'}")
+        for d in (-4, -3, -2, -1, 1, 2, 3, 4):
+            if 0 <= i + d < len(nodes):
+                print(f"    [{d:+d}] {short(nodes[i + d][2])}")
     assert kinds.count("MEMCPY") == 0, f"{kinds.count('MEMCPY')} MEMCPY nodes in the captured iteration"
     edges = re.findall(r'"(graph_\d+_node_\d+)"\s*->\s*"(graph_\d+_node_\d+)"', dot)
     assert len(edges) == len(kinds) - 1, "captured iteration is no longer a single chain"
