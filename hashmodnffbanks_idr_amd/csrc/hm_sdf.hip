@@ -151,6 +151,24 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_kernel(HmLevels lv, Sd
         __syncthreads();
 
         // ---------------- layers ------------------------------------------------------------
+        // weight ring (4 slots per feature tile) lives across layers: the first three octets of layer l+1 are
+        // requested before layer l's epilogue (weights do not depend on the activations), so the stream does not
+        // restart from an empty pipe behind the two barriers of every layer
+        float4 r0[4], r1[4];
+        bool ring_ready = false;
+        auto prefetch64 = [&](int l) {
+            const hm_mlp_layer &Lp = net.layer[l];
+            const int nop = Lp.seg_octets[0] + Lp.seg_octets[1];
+            const int ntp = max(0, min(2, Lp.n_tiles - 2 * wave));
+            const float4 *P0 = reinterpret_cast<const float4 *>(Lp.w_packed) + ((size_t)(2 * wave) * nop) * 64 + lane;
+            const float4 *P1 = P0 + (ntp > 1 ? (size_t)nop * 64 : 0);
+#pragma unroll
+            for (int st = 0; st < 3; ++st) {
+                const size_t off = (size_t)min(st, nop - 1) * 64;
+                r0[st] = P0[off];
+                r1[st] = P1[off];
+            }
+        };
         for (int li = 0; li < net.n_layers; ++li) {
             const hm_mlp_layer &Ly = net.layer[li];
             const int n_oct = Ly.seg_octets[0] + Ly.seg_octets[1];
@@ -196,13 +214,8 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_kernel(HmLevels lv, Sd
                 const int no0 = Ly.seg_octets[0];
                 const float *src0 = (Ly.seg_src[0] == 0) ? X : EMB;
                 const float *src1 = (Ly.seg_src[1] == 0) ? X : EMB;
-                float4 r0[4], r1[4];
-#pragma unroll
-                for (int st = 0; st < 3; ++st) {
-                    const size_t off = (size_t)min(st, n_oct - 1) * 64;
-                    r0[st] = A0[off];
-                    r1[st] = A1[off];
-                }
+                if (!ring_ready) prefetch64(li);
+                ring_ready = false;
                 auto octet = [&](int gg, const float4 &a0, const float4 &a1) {
                     const float *src = (gg < no0) ? src0 + (2 * gg + h) * kGroupFloats
                                                   : src1 + (2 * (gg - no0) + h) * kGroupFloats;
@@ -245,6 +258,11 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_kernel(HmLevels lv, Sd
                 if (n_full + 0 < n_oct) octet(n_full + 0, r0[0], r1[0]);
                 if (n_full + 1 < n_oct) octet(n_full + 1, r0[1], r1[1]);
                 if (n_full + 2 < n_oct) octet(n_full + 2, r0[2], r1[2]);
+            }
+            if (li + 1 < net.n_layers && !(li + 1 == net.n_layers - 1 && out_cols == 1) &&
+                net.layer[li + 1].n_tiles - 2 * wave > 0) {
+                prefetch64(li + 1);
+                ring_ready = true;
             }
             __syncthreads();  // every wave has finished reading X / EMB for this layer
 
@@ -1160,8 +1178,9 @@ int hm_sdf_fwd(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *x,
                                as_stream(stream), lv, net, x, n, table, B_fourier, out, out_stride, out_cols, n_dev,
                                lo16, hi16, m8_max, m4_max);
     }
-    // big batches: two 32-point workgroups per CU (default) or one 64-point workgroup (HM_SDF_P32=0)
-    static const int use_p32 = [] { const char *e = getenv("HM_SDF_P32"); return e ? atoi(e) : 1; }();
+    // big batches: one 64-point workgroup per CU; HM_SDF_P32=1 / tile_points 32: two 32-point workgroups per CU
+    // (measured SLOWER: 113 vs 121.6 TFLOP/s - twice the weight stream per MFMA costs more than the overlap gains)
+    static const int use_p32 = [] { const char *e = getenv("HM_SDF_P32"); return e ? atoi(e) : 0; }();
     const size_t lds32 = sizeof(float) * ((size_t)(net.x_groups + net.emb_groups) * kGroupFloats32 + kPts32 * 4 +
                                           2 * kWaves32 * kPts32);
     if (run64 && (use_p32 || tile_points == 32) && tile_points != 64 && lds32 <= 80 * 1024) {

@@ -34,13 +34,18 @@ class _IdrLossHip(torch.autograd.Function):
                                           _lib.dptr(d_grad), _lib.stream_ptr(rgb)))
         ctx.save_for_backward(d_rgb, d_sdf, d_grad)
         ctx.sdf_shape = sdf.shape
-        return terms
+        # the loss leaves as its OWN tensor: indexing terms[0] outside would put a SelectBackward node in front of this
+        # one, whose zeros + copy_ of one float is a MEMCPY node in a captured graph (kernel copy here)
+        from .. import ops
+        loss = ops.dcopy_(torch.empty(1, dtype=torch.float32, device=rgb.device), terms[0:1])
+        ctx.mark_non_differentiable(terms)
+        return loss.reshape(()), terms
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, d_terms):
+    def backward(ctx, d_loss, _d_terms):
         d_rgb, d_sdf, d_grad = ctx.saved_tensors
-        g = d_terms[0]
+        g = d_loss
         return (d_rgb * g, (d_sdf * g).reshape(ctx.sdf_shape), d_grad * g if d_grad is not None else None,
                 None, None, None, None, None, None)
 
@@ -48,12 +53,12 @@ class _IdrLossHip(torch.autograd.Function):
 def idr_loss_terms(model_outputs, rgb_gt, eikonal_weight, mask_weight, alpha):
     if model_outputs['rgb_values'].is_cuda:
         gt = model_outputs['grad_theta']
-        terms = _IdrLossHip.apply(model_outputs['rgb_values'], model_outputs['sdf_output'],
+        loss, terms = _IdrLossHip.apply(model_outputs['rgb_values'], model_outputs['sdf_output'],
                                   gt if (gt is not None and gt.shape[0] > 0) else None, rgb_gt,
                                   model_outputs['network_object_mask'], model_outputs['object_mask'],
                                   eikonal_weight, mask_weight, alpha)
         det = terms.detach()
-        return {'loss': terms[0], 'rgb_loss': det[1], 'eikonal_loss': det[2], 'mask_loss': det[3]}
+        return {'loss': loss, 'rgb_loss': det[1], 'eikonal_loss': det[2], 'mask_loss': det[3]}
     return idr_loss_terms_torch(model_outputs, rgb_gt, eikonal_weight, mask_weight, alpha)
 
 
