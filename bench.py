@@ -353,7 +353,8 @@ def main():
     ap.add_argument("--legs", choices=["both", "fixed", "train"], default="both",
                     help="fixed = section-8(d) workload (weights stay at geometric init; the headline); train = lr 1e-4")
     ap.add_argument("--gather-log2n", type=int, default=22)
-    ap.add_argument("--only", choices=["gather", "gather_bwd", "mlp"], default=None,
+    ap.add_argument("--calib", default="1,0", help="gather_calib: lanes per 128-B block, byte stride between them")
+    ap.add_argument("--only", choices=["gather", "gather_bwd", "mlp", "gather_calib"], default=None,
                     help="profiling helper: run just one kernel section on cuda:0 and print its object")
     ap.add_argument("--cfg", default=None,
                     help="hash-grid config (tests/golden/params.py): default C2 = BASELINE configs[1]; C4 = configs[3] "
@@ -361,6 +362,21 @@ def main():
     args = ap.parse_args()
     cfg = args.cfg or os.environ.get("HM_BENCH_CFG") or ("C4" if args.gpus == 8 else CFG)
 
+    if args.only == "gather_calib":
+        # PMC calibration of 8-byte gathers (run under rocprofv3 --pmc ...; see profiles/README.md)
+        from hashmodnffbanks_idr_amd import _lib
+        dev = torch.device("cuda", 0)
+        group, stride = (int(v) for v in args.calib.split(","))
+        table = torch.zeros((4 << 30) // 4, dtype=torch.float32, device=dev)      # 4 GiB >> 256 MiB Infinity Cache
+        n = 1 << 24
+        out = torch.empty(n, dtype=torch.float32, device=dev)
+        for _ in range(5):
+            _lib.check(_lib.lib().hm_diag_gather_calib(_lib.dptr(table), table.numel() * 4, n, group, stride,
+                                                       _lib.dptr(out), _lib.stream_ptr(out)))
+        torch.cuda.synchronize()
+        print(json.dumps({"kernel": "gather_calib_kernel", "lanes": n, "group": group, "stride_bytes": stride,
+                          "blocks_per_launch": n // group, "rows_bytes_per_launch": n * 8, "launches": 5}))
+        return
     if args.only:
         dev = torch.device("cuda", 0)
         model = _build(cfg, dev, 0.0)

@@ -26,7 +26,10 @@ SIGNATURES = {
     "hm_grid_desc_destroy": (None, [_p]),
     "hm_grid_embed_dim": (_int, [_p]),
     "hm_corner_ids": (_int, [_p, _int, _p, _i64, _p, _p, _p]),
+    "hm_diag_gather_calib": (_int, [_p, _i64, _i64, _int, _int, _p, _p]),
     "hm_encode_fwd": (_int, [_p, _p, _i64, _p, _p, _p, _i64, _int, _p]),
+    "hm_encode_workspace_bytes": (_i64, [_p, _i64]),
+    "hm_encode_fwd_ws": (_int, [_p, _p, _i64, _p, _p, _p, _i64, _int, _p, _i64, _p]),
     "hm_encode_bwd_table": (_int, [_p, _p, _i64, _p, _i64, _p, _int, _p]),
     "hm_sdf_fwd": (_int, [_p, _p, _p, _i64, _p, _p, _p, _i64, _int, _int, _int, _p, _int, _p]),
     "hm_trace_workspace_bytes": (_i64, [_i64, _p]),
@@ -39,6 +42,7 @@ SIGNATURES = {
     "hm_colsum_acc": (_int, [_p, _i64, _i64, _i64, _p, _p]),
     "hm_copy2d_f32": (_int, [_p, _i64, _p, _i64, _i64, _i64, _p]),
     "hm_idr_loss": (_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, C.c_float, C.c_float, C.c_float, _p, _p, _p, _p, _p]),
+    "hm_adam_scratch_floats": (_i64, [_p, _int]),
     "hm_adam_step": (_int, [_p, _int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _p, _p]),
     "hm_gemm_f32_ep": (_int, [_int, _int, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _p]),
     "hm_gemm_f32": (_int, [_int, _int, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _int, _p]),

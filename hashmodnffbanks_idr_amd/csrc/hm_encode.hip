@@ -301,6 +301,180 @@ __global__ __launch_bounds__(kThreadsS) void encode_fwd_f2_sweep_kernel(HmLevels
 }
 
 
+// ---------------------------------------------------------------------------------------------------------
+// z-ordered variant for big launches.  The reference hash multiplies x by 1, y by 3 and only z by the large prime
+// (hashGridEmbedding.py:14,32-40): for one z-plane of a level all (x, y) corners fall into a window of 2^11 rows
+// (16 KB) around (P * uz) mod rows, because ux ^ 3uy only touches the low 11 bits (res <= 512).  Points that are
+// close in z therefore share their table windows on EVERY level.  The launch buckets the points into kSlabs z-slabs
+// (three small passes: histogram, scan, scatter of point indices), and the gather kernel walks the points in that
+// order - consecutive tiles of one XCD read a few 16-KB windows per level out of its L2 instead of scattering over
+// 4 ... 33 MB per level.  x is read and the output rows are written through the permutation (rows keep their
+// positions: out[i] is still encode(x[i])).  Fabric reads per launch at T = 2^22 drop from 9.4 GB to the compulsory
+// traffic; see DESIGN.md / profiles for the measured numbers.
+constexpr int kSlabs = 512;
+constexpr int kSortChunk = 16384;   // points per workgroup of the bucketing passes
+
+__device__ __forceinline__ int z_slab(float z) {
+    const float t = (z + 1.0f) * (0.5f * kSlabs);          // [-1, 1] -> [0, kSlabs); everything outside clamps
+    return (int)fminf(fmaxf(t, 0.0f), (float)(kSlabs - 1));
+}
+
+__global__ __launch_bounds__(1024) void zsort_hist_kernel(const float *__restrict__ x, int64_t n, uint32_t *hist) {
+    __shared__ uint32_t h[kSlabs];
+    for (int i = threadIdx.x; i < kSlabs; i += 1024) h[i] = 0u;
+    __syncthreads();
+    const int64_t beg = (int64_t)blockIdx.x * kSortChunk, end = min(beg + kSortChunk, n);
+    for (int64_t i = beg + threadIdx.x; i < end; i += 1024) atomicAdd(&h[z_slab(x[i * 3 + 2])], 1u);
+    __syncthreads();
+    for (int i = threadIdx.x; i < kSlabs; i += 1024)
+        if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+
+__global__ __launch_bounds__(kSlabs) void zsort_scan_kernel(uint32_t *hist /* in: counts, out: start offsets */) {
+    __shared__ uint32_t s[kSlabs];
+    const int t = threadIdx.x;
+    s[t] = hist[t];
+    __syncthreads();
+    for (int o = 1; o < kSlabs; o <<= 1) {
+        const uint32_t v = t >= o ? s[t - o] : 0u;
+        __syncthreads();
+        s[t] += v;
+        __syncthreads();
+    }
+    hist[t] = s[t] - hist[t];   // exclusive
+}
+
+__global__ __launch_bounds__(1024) void zsort_scatter_kernel(const float *__restrict__ x, int64_t n, uint32_t *cursor,
+                                                             uint32_t *__restrict__ order) {
+    __shared__ uint32_t h[kSlabs], base[kSlabs];
+    for (int i = threadIdx.x; i < kSlabs; i += 1024) h[i] = 0u;
+    __syncthreads();
+    const int64_t beg = (int64_t)blockIdx.x * kSortChunk, end = min(beg + kSortChunk, n);
+    for (int64_t i = beg + threadIdx.x; i < end; i += 1024) atomicAdd(&h[z_slab(x[i * 3 + 2])], 1u);
+    __syncthreads();
+    for (int i = threadIdx.x; i < kSlabs; i += 1024) {
+        base[i] = h[i] ? atomicAdd(&cursor[i], h[i]) : 0u;   // reserve this workgroup's range of the slab
+        h[i] = 0u;
+    }
+    __syncthreads();
+    for (int64_t i = beg + threadIdx.x; i < end; i += 1024) {
+        const int sl = z_slab(x[i * 3 + 2]);
+        order[base[sl] + atomicAdd(&h[sl], 1u)] = (uint32_t)i;
+    }
+}
+
+template <int FRAC>
+__global__ __launch_bounds__(kThreadsS) void encode_fwd_f2_zorder_kernel(HmLevels lv, const float *__restrict__ x,
+                                                                         int64_t n, const float2 *__restrict__ table,
+                                                                         const float *__restrict__ Bf,
+                                                                         float *__restrict__ out, int64_t out_stride,
+                                                                         const uint32_t *__restrict__ order) {
+    extern __shared__ __align__(16) float smem[];
+    const int L = lv.L;
+    const bool fourier = (Bf != nullptr);
+    const int hoff = fourier ? 3 + 2 * L : 0;
+    const int E = hoff + 2 * L;
+    float *s_out = smem;                                                // [kTileS][E]
+    float *s_x = smem + kTileS * E;                                     // [kTileS][3]
+    uint32_t *s_i = reinterpret_cast<uint32_t *>(s_x + kTileS * 3);     // [kTileS] original row of each point
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int corner = lane & 7, sub = lane >> 3;
+    const int bx = corner & 1, by = (corner >> 1) & 1, bz = (corner >> 2) & 1;
+    const int64_t n_tiles = (n + kTileS - 1) / kTileS;
+    const int half = (L + 1) / 2;
+    // XCD-affine tile order: workgroups b and b + 8 share an XCD (round-robin dispatch; speed only, never
+    // correctness).  XCD k walks the k-th eighth of the z-ordered tiles, its workgroups side by side, so that
+    // an XCD's L2 sees one narrow z-range at a time.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = (int)(gridDim.x >> 3);
+    const int64_t span = (n_tiles + 7) / 8;
+
+    for (int64_t k = slot; k < span; k += max(per_xcd, 1)) {
+        const int64_t tile = (int64_t)xcd * span + k;
+        if (tile >= n_tiles) break;
+        const int64_t base = tile * kTileS;
+        const int cnt = (int)min((int64_t)kTileS, n - base);
+        __syncthreads();   // the previous tile's rows have left s_out
+        if (tid < kTileS) s_i[tid] = tid < cnt ? order[base + tid] : 0u;
+        __syncthreads();
+        for (int i = tid; i < kTileS * 3; i += kThreadsS) {
+            const int p = i / 3, c = i - p * 3;
+            s_x[i] = (p < cnt) ? x[(int64_t)s_i[p] * 3 + c] : 0.0f;
+        }
+        __syncthreads();
+        if (fourier) {
+            const int p = tid & (kTileS - 1);
+            const int cg = tid / kTileS;  // 0..1
+            const float x0 = s_x[p * 3 + 0], x1 = s_x[p * 3 + 1], x2 = s_x[p * 3 + 2];
+            float *o = s_out + p * E;
+            if (cg == 0) {
+                o[0] = x0; o[1] = x1; o[2] = x2;
+            }
+            const float two_pi = 6.283185307179586f;
+            const float s0 = __fmul_rn(two_pi, x0), s1 = __fmul_rn(two_pi, x1), s2 = __fmul_rn(two_pi, x2);
+            for (int c = cg; c < L; c += 2) {
+                float a = __fmul_rn(s0, Bf[c]);
+                a = __fmaf_rn(s1, Bf[L + c], a);
+                a = __fmaf_rn(s2, Bf[2 * L + c], a);
+                float sn, cs;
+                sincosf(a, &sn, &cs);
+                o[3 + c] = sn;
+                o[3 + L + c] = cs;
+            }
+        }
+        for (int lp = 0; lp < half; ++lp) {
+            const int lvl[2] = {lp, lp + half};
+            float2 v[2][4];
+            float w[2][4];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int l = min(lvl[kk], L - 1);
+                const int32_t res = lv.res[l];
+                const uint32_t rows = lv.rows[l], magic = lv.magic[l];
+                const float2 *tl = table + lv.row_off[l];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int p = wave * 32 + j * 8 + sub;
+                    uint32_t ux, uy, uz;
+                    float wx, wy, wz;
+                    voxel_and_weight<FRAC>(s_x[p * 3 + 0], res, bx, ux, wx);
+                    voxel_and_weight<FRAC>(s_x[p * 3 + 1], res, by, uy, wy);
+                    voxel_and_weight<FRAC>(s_x[p * 3 + 2], res, bz, uz, wz);
+                    v[kk][j] = tl[hm_mod_rows(hm_hash3(ux, uy, uz), rows, magic)];
+                    w[kk][j] = __fmul_rn(__fmul_rn(wx, wy), wz);
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                if (lvl[kk] >= L) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float a0 = __fmul_rn(v[kk][j].x, w[kk][j]);
+                    float a1 = __fmul_rn(v[kk][j].y, w[kk][j]);
+                    a0 = dpp_add_xor1(a0); a1 = dpp_add_xor1(a1);
+                    a0 = dpp_add_xor2(a0); a1 = dpp_add_xor2(a1);
+                    a0 = dpp_add_half_mirror(a0); a1 = dpp_add_half_mirror(a1);
+                    if (corner == 0) {
+                        float *o = s_out + (wave * 32 + j * 8 + sub) * E + hoff + 2 * lvl[kk];
+                        o[0] = a0;
+                        o[1] = a1;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // rows go back to their ORIGINAL positions: half a wave writes one row as contiguous dwords (nt: streamed)
+        {
+            const int hw = tid >> 5, hl = tid & 31;   // 16 half-waves
+            for (int p = hw; p < cnt; p += kThreadsS / 32) {
+                float *dst = out + (int64_t)s_i[p] * out_stride;
+                const float *src = s_out + p * E;
+                for (int c = hl; c < E; c += 32) __builtin_nontemporal_store(src[c], dst + c);
+            }
+        }
+    }
+}
+
 template <int FRAC>
 __global__ __launch_bounds__(kThreads) void encode_fwd_generic_kernel(HmLevels lv, const float *__restrict__ x,
                                                                       int64_t n, const float *__restrict__ table,
@@ -394,11 +568,45 @@ __global__ __launch_bounds__(kThreads) void encode_bwd_table_kernel(HmLevels lv,
     for (int f = 0; f < F; ++f) atomicAdd(row + f, __fmul_rn(w, g[f]));
 }
 
+// Counter calibration for 8-byte row gathers (diagnostic; bench.py --only gather_calib).  Every group of `group`
+// consecutive lanes reads 8-byte rows of ONE pseudo-random 128-B-aligned block of a table far larger than the
+// Infinity Cache, lane g of the group at byte offset g * stride_bytes inside the block: the ALGORITHMIC bytes and the
+// set of 32- / 64- / 128-byte units touched are known exactly, so FETCH_SIZE / TCC_EA0_RDREQ per block tell the
+// fetch granularity and the counter's unit for this access shape (the guide calibrates wide coalesced loads only).
+__global__ __launch_bounds__(256) void gather_calib_kernel(const float2 *__restrict__ table, uint64_t n_blocks,
+                                                           int64_t n, int group, int stride_bytes,
+                                                           float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint64_t b = (uint64_t)(i / group);
+    b = (b ^ (b >> 31)) * 0x9E3779B97F4A7C15ull;       // splitmix-style scramble: distinct blocks, no locality
+    b = (b ^ (b >> 29)) * 0xBF58476D1CE4E5B9ull;
+    b = (b ^ (b >> 32)) % n_blocks;
+    const int g = (int)(i % group);
+    const float2 v = table[b * 16 + (uint64_t)(g * stride_bytes) / 8];
+    out[i] = v.x + v.y;
+}
+
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 }  // namespace
 
 extern "C" {
+
+int hm_diag_gather_calib(const float *table, int64_t table_bytes, int64_t n, int group, int stride_bytes, float *out,
+                         void *stream) {
+    HM_CHECK_ARG(table && out && n > 0 && table_bytes >= 128, "hm_diag_gather_calib: bad argument");
+    HM_CHECK_ARG(group >= 1 && group <= 16 && stride_bytes >= 0 && stride_bytes % 8 == 0 &&
+                     (group - 1) * stride_bytes + 8 <= 128,
+                 "hm_diag_gather_calib: the group's rows must stay inside one 128-B block");
+    const int64_t grid = (n + 255) / 256;
+    HM_CHECK_ARG(grid <= 0x7fffffffLL, "hm_diag_gather_calib: n too large");
+    hipLaunchKernelGGL(gather_calib_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float2 *>(table), (uint64_t)(table_bytes / 128), n, group, stride_bytes,
+                       out);
+    HM_CHECK_LAUNCH("hm_diag_gather_calib");
+    return HM_OK;
+}
 
 int hm_corner_ids(const hm_grid_desc *desc, int level, const float *x, int64_t n, int32_t *xi_out,
                   uint32_t *ids_out, void *stream) {
@@ -415,8 +623,30 @@ int hm_corner_ids(const hm_grid_desc *desc, int level, const float *x, int64_t n
     return HM_OK;
 }
 
+int64_t hm_encode_workspace_bytes(const hm_grid_desc *desc, int64_t n) {
+    if (!desc || n < 0) return hm_fail(HM_ERR_INVALID, "hm_encode_workspace_bytes: bad argument");
+    return (int64_t)sizeof(uint32_t) * (n + 2 * kSlabs);
+}
+
+static int encode_fwd_impl(const hm_grid_desc *desc, const float *x, int64_t n, const float *table,
+                           const float *B_fourier, float *out, int64_t out_stride, int frac_mode, void *workspace,
+                           int64_t workspace_bytes, void *stream);
+
 int hm_encode_fwd(const hm_grid_desc *desc, const float *x, int64_t n, const float *table, const float *B_fourier,
                   float *out, int64_t out_stride, int frac_mode, void *stream) {
+    return encode_fwd_impl(desc, x, n, table, B_fourier, out, out_stride, frac_mode, nullptr, 0, stream);
+}
+
+int hm_encode_fwd_ws(const hm_grid_desc *desc, const float *x, int64_t n, const float *table, const float *B_fourier,
+                     float *out, int64_t out_stride, int frac_mode, void *workspace, int64_t workspace_bytes,
+                     void *stream) {
+    return encode_fwd_impl(desc, x, n, table, B_fourier, out, out_stride, frac_mode, workspace, workspace_bytes,
+                           stream);
+}
+
+static int encode_fwd_impl(const hm_grid_desc *desc, const float *x, int64_t n, const float *table,
+                           const float *B_fourier, float *out, int64_t out_stride, int frac_mode, void *workspace,
+                           int64_t workspace_bytes, void *stream) {
     HM_CHECK_ARG(desc != nullptr, "hm_encode_fwd: desc is NULL");
     HM_CHECK_ARG(n >= 0, "hm_encode_fwd: n < 0");
     HM_CHECK_ARG(frac_mode == HM_FRAC_REFERENCE || frac_mode == HM_FRAC_TRILINEAR, "hm_encode_fwd: bad frac_mode");
@@ -427,11 +657,46 @@ int hm_encode_fwd(const hm_grid_desc *desc, const float *x, int64_t n, const flo
     HM_CHECK_ARG(x && table && out, "hm_encode_fwd: NULL pointer");
     static const int sweep_cfg = [] { const char *e = getenv("HM_ENCODE_SWEEP"); return e ? atoi(e) : 1; }();
     // cache policy of the output-row stores / x loads (see store_tile_vec); HM_ENCODE_FLAGS overrides for experiments
-    static const int enc_flags = [] { const char *e = getenv("HM_ENCODE_FLAGS"); return e ? atoi(e) : 0; }();
-    static const int sweep_grid = [] { const char *e = getenv("HM_ENCODE_GRID"); return e ? atoi(e) : 512; }();
+    // default: nt stores of the output rows (C2 4.61 -> 4.77 TB/s, C4 3.61 -> 3.73; sc1 / nt loads / 4 levels per
+    // step measured equal or slower, profiles/README.md); tables beyond 64 MiB run ONE workgroup per CU (C4: 3.89)
+    static const int enc_flags = [] { const char *e = getenv("HM_ENCODE_FLAGS"); return e ? atoi(e) : 2; }();
+    static const int sweep_grid_env = [] { const char *e = getenv("HM_ENCODE_GRID"); return e ? atoi(e) : 0; }();
+    const int sweep_grid = sweep_grid_env > 0 ? sweep_grid_env
+                                              : (desc->total_rows * (uint64_t)lv.F * 4u > (64u << 20) ? 256 : 512);
     const size_t lds_sweep = sizeof(float) * (size_t)(kTileS * width + kTileS * 3);
     const bool table_exceeds_l2 = desc->total_rows * (uint64_t)lv.F * 4u > (8u << 20);   // (C1's 0.9 MiB: tile kernel)
-    if (lv.F == 2 && sweep_cfg != 0 && table_exceeds_l2 && n >= (int64_t)131072 && lds_sweep <= 160 * 1024) {
+    static const int zorder_cfg = [] { const char *e = getenv("HM_ENCODE_ZORDER"); return e ? atoi(e) : 1; }();
+    const size_t lds_z = sizeof(float) * (size_t)(kTileS * width + kTileS * 3 + kTileS);
+    if (lv.F == 2 && zorder_cfg != 0 && workspace && table_exceeds_l2 && n >= (int64_t)131072 && n < ((int64_t)1 << 32) &&
+        lds_z <= 160 * 1024 && workspace_bytes >= (int64_t)sizeof(uint32_t) * (n + 2 * kSlabs)) {
+        static thread_local bool attr_z = false;
+        if (!attr_z) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_fwd_f2_zorder_kernel<HM_FRAC_REFERENCE>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_fwd_f2_zorder_kernel<HM_FRAC_TRILINEAR>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return hm_fail(HM_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+            attr_z = true;
+        }
+        hipStream_t st = as_stream(stream);
+        uint32_t *hist = static_cast<uint32_t *>(workspace);        // [kSlabs] counts -> start offsets -> cursors
+        uint32_t *order = hist + 2 * kSlabs;                          // [n]
+        hm_zero_u32_async(hist, kSlabs, st);
+        const unsigned g_sort = (unsigned)((n + kSortChunk - 1) / kSortChunk);
+        hipLaunchKernelGGL(zsort_hist_kernel, dim3(g_sort), dim3(1024), 0, st, x, n, hist);
+        hipLaunchKernelGGL(zsort_scan_kernel, dim3(1), dim3(kSlabs), 0, st, hist);
+        hipLaunchKernelGGL(zsort_scatter_kernel, dim3(g_sort), dim3(1024), 0, st, x, n, hist, order);
+        const int64_t tiles = (n + kTileS - 1) / kTileS;
+        static const int z_grid = [] { const char *e = getenv("HM_ENCODE_ZGRID"); return e ? atoi(e) : 512; }();
+        const unsigned grid = (unsigned)(tiles < z_grid ? ((tiles + 7) / 8) * 8 : z_grid);
+        if (frac_mode == HM_FRAC_REFERENCE)
+            hipLaunchKernelGGL(encode_fwd_f2_zorder_kernel<HM_FRAC_REFERENCE>, dim3(grid), dim3(kThreadsS), lds_z, st,
+                               lv, x, n, reinterpret_cast<const float2 *>(table), B_fourier, out, out_stride, order);
+        else
+            hipLaunchKernelGGL(encode_fwd_f2_zorder_kernel<HM_FRAC_TRILINEAR>, dim3(grid), dim3(kThreadsS), lds_z, st,
+                               lv, x, n, reinterpret_cast<const float2 *>(table), B_fourier, out, out_stride, order);
+    } else if (lv.F == 2 && sweep_cfg != 0 && table_exceeds_l2 && n >= (int64_t)131072 && lds_sweep <= 160 * 1024) {
         // big launches over big tables: level-synchronous persistent kernel (two workgroups per CU)
         static thread_local bool attr_done = false;
         if (!attr_done) {

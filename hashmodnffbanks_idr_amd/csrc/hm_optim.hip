@@ -7,7 +7,10 @@
 // one streaming pass over (p, g, m, v) - 16 B read + 16 B written per parameter, HBM-bound and dominated by the
 // 10.4 M-entry hash table - so it is written as one pass:
 //   1. adam_begin_kernel   : zero the norm accumulator, ++step of every tensor that has a gradient
-//   2. grad_sqnorm_kernel  : sum g^2 over every tensor (per-workgroup tree + one atomic)
+//   2. grad_sqnorm_kernel  : sum g^2 over every tensor: per-workgroup tree -> partials[chunk], then ONE workgroup adds
+//                            the partials in a fixed order (norm_finalize_kernel).  No float atomics: the norm - and
+//                            with it the clip coefficient and every updated parameter - is bitwise reproducible, so
+//                            data-parallel replicas fed the same all-reduced gradients stay bitwise identical
 //   3. adam_update_kernel  : g *= clip;  m, v, p updated with torch.optim.Adam's formulas
 // The tensor table travels BY VALUE in the kernel arguments (<= 4 KB, like torch's multi_tensor_apply), so the
 // call can be captured into a HIP graph without any host-written device buffer.
@@ -41,7 +44,7 @@ __device__ __forceinline__ int find_tensor(const AdamTable &tb, int chunk) {
     return lo;
 }
 
-__global__ __launch_bounds__(kOT) void grad_sqnorm_kernel(AdamTable tb, float *norm_sq) {
+__global__ __launch_bounds__(kOT) void grad_sqnorm_kernel(AdamTable tb, float *partials) {
     __shared__ float red[kOT / 64];
     const int ti = find_tensor(tb, blockIdx.x);
     const hm_adam_tensor T = tb.t[ti];
@@ -65,8 +68,23 @@ __global__ __launch_bounds__(kOT) void grad_sqnorm_kernel(AdamTable tb, float *n
     if (threadIdx.x == 0) {
         float s = 0.0f;
         for (int w = 0; w < kOT / 64; ++w) s += red[w];
-        atomicAdd(norm_sq, s);
+        partials[blockIdx.x] = s;
     }
+}
+
+// fixed-order sum of the per-chunk partial sums (double accumulators: thread t adds partials t, t+1024, ...; then
+// a fixed tree) -> *norm_sq.  One workgroup; a few thousand partials at most (29 M-row table: 7153 chunks).
+__global__ __launch_bounds__(1024) void norm_finalize_kernel(const float *partials, int n, float *norm_sq) {
+    __shared__ double red[1024];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 1024) acc += (double)partials[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *norm_sq = (float)red[0];
 }
 
 struct AdamHyper {
@@ -127,6 +145,16 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 
 extern "C" {
 
+int64_t hm_adam_scratch_floats(const hm_adam_tensor *tensors, int n_tensors) {
+    if (n_tensors < 0 || (n_tensors > 0 && !tensors)) return hm_fail(HM_ERR_INVALID, "hm_adam_scratch_floats: bad argument");
+    int64_t chunks = 0;
+    for (int i = 0; i < n_tensors; ++i) {
+        if (tensors[i].numel < 0) return hm_fail(HM_ERR_INVALID, "hm_adam_scratch_floats: negative numel");
+        chunks += (tensors[i].numel + kChunk - 1) / kChunk;
+    }
+    return 2 + chunks;
+}
+
 int hm_adam_step(const hm_adam_tensor *tensors, int n_tensors, float lr, float beta1, float beta2, float eps,
                  float max_norm, float *scratch_dev, void *stream) {
     HM_CHECK_ARG(n_tensors >= 0, "hm_adam_step: negative tensor count");
@@ -166,14 +194,18 @@ int hm_adam_step(const hm_adam_tensor *tensors, int n_tensors, float lr, float b
         first = next;
     }
     if (max_norm > 0.0f) {
+        int64_t n_part = 0;
         for (int first = 0; first < n_tensors;) {
             const int next = fill(first, tb);
             HM_CHECK_ARG(next > first, "hm_adam_step: tensor too large for one launch");
             if (tb.n > 0)
                 hipLaunchKernelGGL(grad_sqnorm_kernel, dim3((unsigned)tb.chunk_start[tb.n]), dim3(kOT), 0, st, tb,
-                                   scratch_dev);
+                                   scratch_dev + 2 + n_part);
+            n_part += tb.chunk_start[tb.n];
             first = next;
         }
+        HM_CHECK_ARG(n_part < 0x7fffffff, "hm_adam_step: too many chunks");
+        hipLaunchKernelGGL(norm_finalize_kernel, dim3(1), dim3(1024), 0, st, scratch_dev + 2, (int)n_part, scratch_dev);
     }
     for (int first = 0; first < n_tensors;) {
         const int next = fill(first, tb);

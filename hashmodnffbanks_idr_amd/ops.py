@@ -77,6 +77,9 @@ def corner_ids(desc, level, x):
     return xi, ids.long() & 0xFFFFFFFF
 
 
+_ENC_WS = {}   # device -> scratch of the z-ordered encode (grown on demand, reused by every launch on that stream)
+
+
 def encode_fwd(desc, x, table, B, frac_mode=0, hash_only=False):
     """[N,E] embedding (or [N,L*F] hash features when hash_only) - no autograd."""
     x = _prep_x(x)
@@ -86,8 +89,16 @@ def encode_fwd(desc, x, table, B, frac_mode=0, hash_only=False):
     width = desc.L * desc.F if hash_only else desc.E
     out = torch.empty((n, width), dtype=torch.float32, device=x.device)
     Bp = None if hash_only else B.contiguous()
-    check(lib().hm_encode_fwd(desc.handle, dptr(x), n, dptr(table), dptr(Bp), dptr(out), width, int(frac_mode),
-                              stream_ptr(x)))
+    if n >= 131072:     # big launches: z-ordered gather (needs scratch for the point permutation)
+        need = check(lib().hm_encode_workspace_bytes(desc.handle, n))
+        ws = _ENC_WS.get(x.device)
+        if ws is None or ws.numel() < need:
+            ws = _ENC_WS[x.device] = torch.empty(need, dtype=torch.uint8, device=x.device)
+        check(lib().hm_encode_fwd_ws(desc.handle, dptr(x), n, dptr(table), dptr(Bp), dptr(out), width, int(frac_mode),
+                                     dptr(ws), ws.numel(), stream_ptr(x)))
+    else:
+        check(lib().hm_encode_fwd(desc.handle, dptr(x), n, dptr(table), dptr(Bp), dptr(out), width, int(frac_mode),
+                                  stream_ptr(x)))
     return out
 
 

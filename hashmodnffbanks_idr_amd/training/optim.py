@@ -32,7 +32,10 @@ class ClipAdam(torch.optim.Optimizer):
         st = self._dev_state.get(dev)
         if st is None:
             n = sum(len(g["params"]) for g in self.param_groups)
-            st = (torch.zeros(n, dtype=torch.int64, device=dev), torch.zeros(2, dtype=torch.float32, device=dev))
+            # scratch: [norm^2, norm] + one partial sum per 8192 gradient elements (hm_adam_scratch_floats), sized for
+            # ALL parameters once so that its address never changes (the step may sit in a captured graph)
+            n_scratch = 2 + sum((p.numel() + 8191) // 8192 for g in self.param_groups for p in g["params"])
+            st = (torch.zeros(n, dtype=torch.int64, device=dev), torch.zeros(n_scratch, dtype=torch.float32, device=dev))
             self._dev_state[dev] = st
         return st
 
@@ -70,6 +73,9 @@ class ClipAdam(torch.optim.Optimizer):
             table[i] = _lib.AdamTensor(p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(),
                                        st["exp_avg_sq"].data_ptr(), steps.data_ptr() + 8 * k, p.numel())
         b1, b2 = grp["betas"]
+        need = check(lib().hm_adam_scratch_floats(C.cast(table, C.c_void_p), len(plist)))
+        if need > scratch.numel():
+            raise RuntimeError("ClipAdam: scratch buffer too small (parameter list changed after the first step?)")
         check(lib().hm_adam_step(C.cast(table, C.c_void_p), len(plist), float(grp["lr"]), float(b1), float(b2),
                                  float(grp["eps"]), float(self.max_norm) if self.max_norm else 0.0,
                                  C.c_void_p(scratch.data_ptr()), _lib.stream_ptr(plist[0][1])))

@@ -68,6 +68,14 @@ HM_API int hm_grid_embed_dim(const hm_grid_desc *desc); /* 3 + 2L + L*F (hashGri
 HM_API int hm_corner_ids(const hm_grid_desc *desc, int level, const float *x, int64_t n, int32_t *xi_out,
                   uint32_t *ids_out, void *stream);
 
+/* ---- diagnostic: PMC calibration of 8-byte row gathers ---------------------------------------------
+ * Not part of the reference's interface.  Groups of `group` consecutive lanes read 8-byte rows of one pseudo-random
+ * 128-B block of `table` (table_bytes >> Infinity Cache), lane g at byte offset g*stride_bytes: known bytes and
+ * known 32/64/128-B units per block, against which FETCH_SIZE / TCC_EA0_RDREQ are read (profiles/r02_gather_calib.json).
+ * out [n] receives a checksum per lane.                                                                  */
+HM_API int hm_diag_gather_calib(const float *table, int64_t table_bytes, int64_t n, int group, int stride_bytes,
+                                float *out, void *stream);
+
 /* ---- encoder forward --------------------------------------------------------------------
  * Replaces MultiResHashGridMLP.forward (hashGridEmbedding.py:150-155) including
  * FourierFeature.forward (frequency_enc.py:63-67):
@@ -78,6 +86,16 @@ HM_API int hm_corner_ids(const hm_grid_desc *desc, int level, const float *x, in
  * (the torch.cat([level(x) ...]) half of hashGridEmbedding.py:153).                            */
 HM_API int hm_encode_fwd(const hm_grid_desc *desc, const float *x, int64_t n, const float *table,
                   const float *B_fourier, float *out, int64_t out_stride, int frac_mode, void *stream);
+
+/* Same operator with a caller-owned scratch buffer of hm_encode_workspace_bytes(desc, n) bytes.  Big launches
+ * (n >= 131072 over tables larger than 8 MiB) then bucket the points by z first and gather in that order: the
+ * reference hash puts every (x, y) corner of one z-plane into one 16-KB window of a level's table, so z-ordered
+ * points share their table lines on every level (out[i] is still the embedding of x[i]; only the order of the
+ * work changes).  Without a workspace (or for small launches) the call is identical to hm_encode_fwd.          */
+HM_API int64_t hm_encode_workspace_bytes(const hm_grid_desc *desc, int64_t n);
+HM_API int hm_encode_fwd_ws(const hm_grid_desc *desc, const float *x, int64_t n, const float *table,
+                     const float *B_fourier, float *out, int64_t out_stride, int frac_mode, void *workspace,
+                     int64_t workspace_bytes, void *stream);
 
 /* ---- encoder backward (table) -----------------------------------------------------------
  * Replaces the embedding_dense_backward that autograd runs for nn.Embedding in
@@ -263,14 +281,18 @@ HM_API int hm_idr_loss(const float *rgb, const float *rgb_gt, const float *sdf, 
  * (training/idr_train.py:128,306-309; amsgrad / weight decay off as in the reference) over all tensors in
  * three launches.  In place: grad *= clip coefficient, exp_avg, exp_avg_sq, param.  max_norm <= 0 skips the
  * clipping.  Every tensor's step counter is incremented by the call (the bias corrections use the incremented
- * value); tensors left out of a call (no gradient) keep theirs, as in torch.  scratch_dev: 2 device floats; scratch_dev[1] receives the total gradient norm
- * (before clipping) when max_norm > 0.  Sync-free and graph-capturable.                              */
+ * value); tensors left out of a call (no gradient) keep theirs, as in torch.  scratch_dev: hm_adam_scratch_floats()
+ * device floats (2 + one partial sum per 8192 gradient elements); scratch_dev[1] receives the total gradient norm
+ * (before clipping) when max_norm > 0.  The norm is summed in a fixed order (no float atomics): the whole update is
+ * bitwise reproducible, so data-parallel replicas fed the same all-reduced gradients stay bitwise identical.
+ * Sync-free and graph-capturable.                                                                     */
 #define HM_ADAM_MAX_TENSORS 64
 typedef struct hm_adam_tensor {
     float *param, *grad, *exp_avg, *exp_avg_sq;  /* device, fp32, contiguous, same numel */
     int64_t *step;                               /* device iteration counter of THIS tensor (torch: state['step']) */
     int64_t numel;
 } hm_adam_tensor;
+HM_API int64_t hm_adam_scratch_floats(const hm_adam_tensor *tensors, int n_tensors);
 HM_API int hm_adam_step(const hm_adam_tensor *tensors, int n_tensors, float lr, float beta1, float beta2, float eps,
                         float max_norm, float *scratch_dev, void *stream);
 

@@ -1,0 +1,137 @@
+"""Ray-sharded data parallelism on the real model: two ranks (gloo backend, both on cuda:0 - RCCL refuses two ranks
+per device) run the captured training step with the gradient all-reduce between the two graphs; a single process
+fed the AVERAGED per-shard gradients must follow the same trajectory - parameters, loss and the ray tracer's
+counters of rank 0 (the 4-rank rehearsal's `sdf_evals = 2 * rays` needed an explanation; the
+non-finite-SDF counter of the tracer is asserted 0 on every rank and step here)."""
+import os
+import socket
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+N_RAYS, STEPS, LR = 512, 5, 1.0e-4
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _build():
+    import bench
+    from helpers import idr_conf
+    from hashmodnffbanks_idr_amd.model.implicit_differentiable_renderer import IDRNetwork
+    from hashmodnffbanks_idr_amd.model.loss import IDRLoss
+    torch.manual_seed(0)
+    model = IDRNetwork(idr_conf("C1")).cuda()
+    with torch.no_grad():  # let the hash features matter
+        model.implicit_network.lin0.weight_v[:, 3:].normal_(0, 0.02)
+        model.implicit_network.embed_model.embedder_obj.table.uniform_(-0.05, 0.05)
+    model.train()
+    return model, IDRLoss(eikonal_weight=0.1, mask_weight=100.0, alpha=50.0), bench
+
+
+def _shard_inputs(bench, rank):
+    inp, gt = bench.synthetic_batch(1234 + rank, N_RAYS, "cuda")
+    rs = np.random.RandomState(40 + rank)
+    inp["object_mask"] = torch.from_numpy(rs.uniform(0, 1, (1, N_RAYS)) < 0.8).cuda()
+    gt["rgb"] = torch.from_numpy(rs.uniform(-1, 1, (1, N_RAYS, 3)).astype(np.float32)).cuda()
+    return inp, gt
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), HM_DIST_BACKEND="gloo")
+    from hashmodnffbanks_idr_amd import parallel
+    from hashmodnffbanks_idr_amd.training.graph_step import GraphedTrainStep
+    from hashmodnffbanks_idr_amd.training.optim import ClipAdam
+    parallel.init_distributed()
+    torch.cuda.set_device(0)
+    model, loss_fn, bench = _build()
+    inp, gt = _shard_inputs(bench, rank)
+    opt = ClipAdam(model.parameters(), lr=LR, max_norm=1.0)
+    stepper = GraphedTrainStep(model, loss_fn, opt, parallel.GradAllReducer(model.parameters()), warmup=2)
+    torch.manual_seed(100 + rank)
+    rec = {"loss": [], "evals": [], "nonfinite": [], "unfinished": []}
+    for _ in range(STEPS):
+        _, lo = stepper.step(inp, gt)
+        st = model.ray_tracer.last_stats
+        rec["loss"].append(float(lo["loss"].item()))
+        rec["evals"].append(int(st["sdf_evals"]))
+        rec["nonfinite"].append(int(st["nonfinite"]))
+        rec["unfinished"].append(int(st["unfinished"]))
+    rec["graph"] = stepper.g_fb is not None
+    rec["params"] = {n: p.detach().cpu() for n, p in model.named_parameters()}
+    torch.save(rec, os.path.join(out_dir, f"rank{rank}.pt"))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def _single_process_reference():
+    """the same two shards in ONE process: per step both shards' gradients, their mean, one clip + Adam step"""
+    from hashmodnffbanks_idr_amd.model.loss import idr_loss_terms
+    from hashmodnffbanks_idr_amd.training.optim import ClipAdam
+    model, loss_fn, bench = _build()
+    shards = [_shard_inputs(bench, r) for r in range(2)]
+    gens = [torch.Generator().manual_seed(100 + r) for r in range(2)]    # the ranks' CPU generator streams
+    opt = ClipAdam(model.parameters(), lr=LR, max_norm=1.0)
+    params = [p for p in model.parameters() if p.requires_grad]
+    rec = {"loss": [], "evals": []}
+    bb = model.object_bounding_sphere
+    for _ in range(STEPS):
+        sums = None
+        for r, (inp, gt) in enumerate(shards):
+            steps = torch.empty(100).uniform_(0.0, 1.0, generator=gens[r]).cuda()
+            eik = torch.empty(N_RAYS // 2, 3).uniform_(-bb, bb, generator=gens[r]).cuda()
+            for p in params:
+                p.grad = None
+            out = model.forward_static(inp, eik, steps)
+            lo = idr_loss_terms(out, gt["rgb"], loss_fn.eikonal_weight, loss_fn.mask_weight, loss_fn.alpha)
+            lo["loss"].backward()
+            if r == 0:
+                rec["loss"].append(float(lo["loss"].item()))
+                rec["evals"].append(int(model.ray_tracer.last_stats["sdf_evals"]))
+            gs = [None if p.grad is None else p.grad.detach().clone() for p in params]
+            sums = gs if sums is None else [a if b is None else (b if a is None else a + b) for a, b in zip(sums, gs)]
+        for p, g in zip(params, sums):
+            p.grad = None if g is None else g / 2.0
+        opt.step()
+    rec["params"] = {n: p.detach().cpu() for n, p in model.named_parameters()}
+    return rec
+
+
+def test_two_gloo_ranks_follow_the_averaged_gradient_trajectory():
+    import torch.multiprocessing as mp
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(2, _free_port(), d), nprocs=2, join=True)
+        ranks = [torch.load(os.path.join(d, f"rank{r}.pt"), weights_only=False) for r in range(2)]
+    ref = _single_process_reference()
+    for r in ranks:
+        assert r["graph"], "graph capture fell back to eager"
+        assert r["nonfinite"] == [0] * STEPS and r["unfinished"] == [0] * STEPS
+    # replicas stay identical across ranks (same averaged gradient, same update)
+    rep = {n: (p - ranks[1]["params"][n]).abs().max().item() for n, p in ranks[0]["params"].items()}
+    print("largest rank-0 / rank-1 parameter differences:", sorted(rep.items(), key=lambda kv: -kv[1])[:4])
+    assert max(rep.values()) == 0.0, "replicas diverged"
+    r0 = ranks[0]
+    print("rank-0 sdf evals per step:", r0["evals"], " single process:", ref["evals"])
+    print("rank-0 loss per step:", [f"{v:.6f}" for v in r0["loss"]], " single process:", [f"{v:.6f}" for v in ref["loss"]])
+    for a, b in zip(r0["evals"], ref["evals"]):
+        assert abs(a - b) <= 0.02 * b + 200, (r0["evals"], ref["evals"])
+    for a, b in zip(r0["loss"], ref["loss"]):
+        assert abs(a - b) <= 2e-3 * abs(b) + 1e-6, (r0["loss"], ref["loss"])
+    worst = 0.0
+    for n, p in r0["params"].items():
+        q = ref["params"][n]
+        diff = (p - q).abs()
+        worst = max(worst, diff.max().item())
+        # Adam's first steps are lr * sign(g): an entry whose gradient is at noise level may go the other way
+        assert diff.max().item() <= 2.5 * STEPS * LR, n
+        assert diff.mean().item() <= 0.05 * LR, (n, diff.mean().item())
+    print(f"max parameter difference after {STEPS} steps: {worst:.2e}")
