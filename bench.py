@@ -154,12 +154,13 @@ def gather_roofline(emb, log2_n=22, iters=10, warmup=3):
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": n * bpp,
-            "kernel": "encode_fwd_f2_sweep_kernel" if (emb.table.numel() * 4 > (8 << 20) and n >= 512 * 256)
-            else "encode_fwd_f2_kernel",
+            "kernel": "encode_fwd_f2_zorder_kernel (+ 3 bucketing passes, inside the timed launch)"
+            if (emb.table.numel() * 4 > (8 << 20) and n >= 512 * 256) else "encode_fwd_f2_kernel",
             "units_per_launch": n, "bytes_per_unit": bpp, "avg_launch_ms": round(avg_ms, 4),
             "min_launch_ms": round(float(ms.min()), 4),
-            "note": f"table {emb.table.numel() * 4 / 2**20:.1f} MiB is Infinity-Cache resident (<256 MiB)"
-                    + ("" if emb.table.numel() * 4 > (32 << 20) else " and L2 resident (32 MiB aggregate)")}
+            "note": f"table {emb.table.numel() * 4 / 2**20:.1f} MiB (< 256 MiB Infinity Cache); big launches walk the points "
+                    "in z order, so the corner rows are served by the L2s: `traffic` (fabric bytes, PMC) is below the "
+                    "algorithmic bytes"}
 
 
 def gather_bwd_roofline(emb, log2_n=22, iters=10, warmup=3):
