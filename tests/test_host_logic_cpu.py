@@ -110,6 +110,70 @@ def test_checkpoint_wire_format(tmp_path):
     assert sched2.last_epoch == sched.last_epoch
     s1, s2 = opt.state_dict()["state"], opt2.state_dict()["state"]
     assert all(torch.equal(s1[i]["exp_avg"], s2[i]["exp_avg"]) for i in s1)
+    # the optimizer file has the REFERENCE's layout: one entry per hash-grid level (levels.{l}.embedding.weight)
+    osd = torch.load(tmp_path / "OptimizerParameters" / "7.pth", weights_only=True)["optimizer_state_dict"]
+    L_sdf = model.implicit_network.embed_model.embedder_obj.n_levels
+    L_view = model.rendering_network.embed_model.embedder_obj.n_levels
+    n_own = len(list(model.parameters()))
+    assert len(osd["param_groups"][0]["params"]) == n_own + (L_sdf - 1) + (L_view - 1)
+    emb = model.implicit_network.embed_model.embedder_obj
+    k_table = [k for k, p in enumerate(model.parameters()) if p is emb.table][0]
+    for l in range(L_sdf):
+        assert osd["state"][k_table + l]["exp_avg"].shape == (int(emb.desc.rows[l]), 2)
+
+
+def test_optimizer_state_from_a_reference_shaped_checkpoint(golden):
+    """A handcrafted optimizer state dict in the reference's shape (its own parameter list: golden param_names of the
+    reference run, one Adam entry per level) loads into ClipAdam / torch.optim.Adam over the fused table, and survives
+    the round trip back (the cross-loading claim must hold for OptimizerParameters too)."""
+    from hashmodnffbanks_idr_amd.model.implicit_differentiable_renderer import IDRNetwork
+    from hashmodnffbanks_idr_amd.training import checkpoints as ck
+    ref_names = [str(n) for n in golden("idr_step_C1")["param_names"]]
+    torch.manual_seed(5)
+    model = IDRNetwork(idr_conf("C1"))
+    layout = ck._reference_layout(model)
+    own_names = [n for n, _ in model.named_parameters()]
+    assert len(layout) == len(ref_names) == 55
+    # same order as the reference's model.parameters(): level entries sit where the fused table sits
+    for (k, rows), rn in zip(layout, ref_names):
+        if rows is None:
+            assert own_names[k] == rn
+        else:
+            assert own_names[k].endswith("embedder_obj.table") and "embedder_obj.levels." in rn
+    ref_shapes = dict(zip(ref_names, [None] * len(ref_names)))
+    sd_model = model.state_dict()
+    rs = np.random.RandomState(0)
+    state = {}
+    for j, rn in enumerate(ref_names):
+        if rn.endswith("dencity_net.beta"):
+            continue                                          # never receives a gradient: no Adam state (reference too)
+        shape = tuple(sd_model[rn].shape)
+        state[j] = {"step": torch.tensor(12.0), "exp_avg": torch.from_numpy(rs.standard_normal(shape).astype(np.float32)),
+                    "exp_avg_sq": torch.from_numpy(rs.uniform(0, 1, shape).astype(np.float32))}
+    ref_sd = {"state": state, "param_groups": [dict(lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False,
+                                                   maximize=False, foreach=None, capturable=False, differentiable=False,
+                                                   fused=None, decoupled_weight_decay=False,
+                                                   params=list(range(len(ref_names))))]}
+    own_sd = ck.optimizer_state_from_reference(model, ref_sd)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    opt.load_state_dict(own_sd)
+    emb = model.implicit_network.embed_model.embedder_obj
+    st = opt.state[emb.table]
+    off = [int(v) for v in emb.desc.row_off]
+    j0 = ref_names.index("implicit_network.embed_model.embedder_obj.levels.0.embedding.weight")
+    for l in range(emb.n_levels):
+        assert torch.equal(st["exp_avg"][off[l]:off[l + 1]], state[j0 + l]["exp_avg"])
+        assert torch.equal(st["exp_avg_sq"][off[l]:off[l + 1]], state[j0 + l]["exp_avg_sq"])
+    assert float(st["step"]) == 12.0
+    back = ck.optimizer_state_to_reference(model, opt.state_dict())
+    assert set(back["state"]) == set(state)
+    for j in state:
+        assert torch.equal(back["state"][j]["exp_avg"], state[j]["exp_avg"]), ref_names[j]
+    # levels that disagree on the step count cannot be fused
+    bad = {"state": {j: dict(v) for j, v in state.items()}, "param_groups": ref_sd["param_groups"]}
+    bad["state"][j0 + 1]["step"] = torch.tensor(13.0)
+    with pytest.raises(ValueError):
+        ck.optimizer_state_from_reference(model, bad)
 
 
 def _rand_rotation(rng):
@@ -180,3 +244,59 @@ def test_scene_dataset(tmp_path):
     centre = -np.linalg.solve(P[:, :3], P[:, 3])
     np.testing.assert_allclose(ds.pose_all[0][:3, 3].numpy(), centre, rtol=1e-4, atol=1e-4)
     assert ds.get_gt_pose().shape == (2, 4, 4) and ds.get_scale_mat().shape == (4, 4)
+
+
+def test_scene_dataset_on_the_reference_dummy_scan():
+    """The reference's own scene (data/dummy/scan0): its cameras.npz unmodified plus 48x64 windows of images / masks 000
+    and 001 (tests/golden/dummy_scan0; data files only).  The npz also stores each view's intrinsics (camera_mat_i)
+    and the inverse projection (world_mat_inv_i), so the P = K [R | t] decomposition the dataset performs
+    (scene_dataset.py:40-52, rend_util.py:25-46 - cv2.decomposeProjectionMatrix in the reference) is checked against
+    the scene's own ground truth, including the scale_mat normalisation of DATA_CONVENTION.md."""
+    import os
+    from PIL import Image
+    from hashmodnffbanks_idr_amd.datasets.scene_dataset import SceneDataset
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dummy_scan0")
+    cams = np.load(os.path.join(root, "cameras.npz"))
+    n_views = len([k for k in cams.files if k.startswith("world_mat_") and "inv" not in k])
+    assert n_views == 11
+
+    class AllViews(SceneDataset):      # the fixture ships two images; the camera file describes all eleven views
+        def _cameras(self, cam_file, scaled):
+            self.n_images, keep = n_views, self.n_images
+            try:
+                yield from super()._cameras(cam_file, scaled)
+            finally:
+                self.n_images = keep
+
+    H, W = 48, 64
+    # layout <root>/<data_dir>/scan<id>: tests/golden / "." / dummy_scan0 does not match 'scan{id}', so link it
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(os.path.join(tmp, "dummy"))
+        os.symlink(root, os.path.join(tmp, "dummy", "scan0"))
+        ds = AllViews(False, "dummy", [H, W], scan_id=0, root=tmp)
+        assert len(ds) == 2 and len(ds.pose_all) == n_views
+        for i in range(n_views):
+            K = cams[f"camera_mat_{i}"].astype(np.float64)
+            S = cams[f"scale_mat_{i}"].astype(np.float64)
+            Winv = cams[f"world_mat_inv_{i}"].astype(np.float64)
+            intr, pose = ds.intrinsics_all[i].numpy().astype(np.float64), ds.pose_all[i].numpy().astype(np.float64)
+            np.testing.assert_allclose(intr[:3, :3], K[:3, :3], rtol=2e-4, atol=5e-2)      # focal ~1875 px
+            centre_world = Winv[:3, 3] / Winv[3, 3]                                        # P C = 0
+            centre_scaled = np.linalg.solve(S, np.append(centre_world, 1.0))[:3]           # scaled frame = S^-1 world
+            np.testing.assert_allclose(pose[:3, 3], centre_scaled, rtol=1e-3, atol=2e-3)
+            R_wc = np.linalg.inv(K[:3, :3]) @ cams[f"world_mat_{i}"].astype(np.float64)[:3, :3]
+            R_wc /= np.cbrt(np.linalg.det(R_wc))
+            np.testing.assert_allclose(pose[:3, :3], R_wc.T, atol=2e-4)                    # camera-to-world rotation
+            assert abs(np.linalg.det(pose[:3, :3]) - 1) < 1e-4
+            # the cameras of a normalised scene look at the unit sphere from outside it
+            assert 1.0 < np.linalg.norm(pose[:3, 3]) < 10.0
+        idx, sample, gt = ds[1]
+        img = np.asarray(Image.open(os.path.join(root, "image", "001.png")))
+        msk = np.asarray(Image.open(os.path.join(root, "mask", "001.png")))
+        np.testing.assert_allclose(gt["rgb"].numpy(), img.reshape(-1, 3) / 255.0 * 2 - 1, atol=1e-6)
+        np.testing.assert_array_equal(sample["object_mask"].numpy(), (msk.reshape(-1) > 127.5))
+        assert 0.3 < sample["object_mask"].float().mean() < 0.7          # the window straddles the silhouette
+        ds.change_sampling_idx(256)
+        _, s2, g2 = ds[0]
+        assert s2["uv"].shape == (256, 2) and g2["rgb"].shape == (256, 3)
