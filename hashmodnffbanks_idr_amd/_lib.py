@@ -32,9 +32,14 @@ SIGNATURES = {
     "hm_encode_fwd_ws": (_int, [_p, _p, _i64, _p, _p, _p, _i64, _int, _p, _i64, _p]),
     "hm_encode_bwd_table": (_int, [_p, _p, _i64, _p, _i64, _p, _int, _p]),
     "hm_sdf_fwd": (_int, [_p, _p, _p, _i64, _p, _p, _p, _i64, _int, _int, _int, _p, _int, _p]),
+    "hm_nffb_fwd": (_int, [_p, _p, _p, _i64, _p, _p, _p, _i64, _int, _p, _p]),
+    "hm_sdf_fwd_emb": (_int, [_p, _p, _i64, _int, _i64, _p, _i64, _int, _int, _p, _int, _p]),
     "hm_trace_workspace_bytes": (_i64, [_i64, _p]),
     "hm_trace_forward": (_int, [_p, _p, _p, _p, _int, _int, _p, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _p, _p, _p,
                                 _i64, _p, _p]),
+    "hm_trace_workspace_bytes_nffb": (_i64, [_i64, _p, _int]),
+    "hm_trace_forward_nffb": (_int, [_p, _p, _p, _p, _p, _int, _int, _p, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _p,
+                                     _p, _p, _i64, _p, _p]),
     "hm_pack_mlp_layer": (_int, [_p, _i64, _p, _int, _int, _int, _p, _p, _p, _p]),
     "hm_softplus": (_int, [_int, _p, _p, _p, _p, _p, _i64, C.c_float, C.c_float, _p]),
     "hm_sdf_head": (_int, [_int, _p, _i64, _i64, C.c_float, _p, _p, _p, _p, _p, _p]),
@@ -71,6 +76,12 @@ class TraceCfg(C.Structure):
     _fields_ = [("object_bounding_sphere", C.c_float), ("sdf_threshold", C.c_float), ("line_search_step", C.c_double),
                 ("line_step_iters", C.c_int32), ("sphere_tracing_iters", C.c_int32), ("n_steps", C.c_int32),
                 ("n_secant_steps", C.c_int32), ("training", C.c_int32)]
+
+
+class NffbDesc(C.Structure):
+    _fields_ = [("n_levels", C.c_int32), ("bound", C.c_float), ("w0", C.c_float), ("style_eps", C.c_float),
+                ("trunk_w", C.c_void_p * 32), ("trunk_b", C.c_void_p * 32), ("out_w", C.c_void_p), ("out_b", C.c_void_p),
+                ("style_w", C.c_void_p), ("style_b", C.c_void_p)]
 
 
 class MlpDesc(C.Structure):

@@ -39,8 +39,20 @@ struct SdfNet {  // by value -> kernarg
     int32_t x_groups;    // k-groups (of 4) in the X region
     int32_t emb_groups;  // k-groups in the EMB region
     float beta;          // Laplace density beta = |beta_param| + beta_min
+    int64_t emb_stride;  // > 0: `x` holds PRECOMPUTED embedding rows (emb_stride floats apart, lv.E used) - the encode
+                         //      phase becomes a tile load (embedders other than the plain hash grid, hm_sdf_fwd_emb)
     hm_mlp_layer layer[HM_MAX_LAYERS];
 };
+
+// tile of precomputed embedding rows -> EMB[(e/4)][p][e%4] (group stride gf floats), zero padded to 4*egroups columns
+__device__ __forceinline__ void load_emb_tile(float *EMB, const float *__restrict__ emb, int64_t stride, int64_t base,
+                                              int cnt, int E, int egroups, int pts, int gf, int tid, int nthreads) {
+    const int epad = egroups * 4;
+    for (int i = tid; i < pts * epad; i += nthreads) {
+        const int p = i / epad, e = i - p * epad;
+        EMB[(e >> 2) * gf + p * 4 + (e & 3)] = (p < cnt && e < E) ? emb[(base + p) * stride + e] : 0.0f;
+    }
+}
 
 // nn.Softplus(beta=100, threshold=20): y = x if 100x > 20 else log1p(exp(100x))/100
 // evaluated as max(z,0) + ln(1 + 2^(-|z| log2 e)) with the native exp2/log2 units (abs error < 1e-7
@@ -104,11 +116,13 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_kernel(HmLevels lv, Sd
         const int64_t base = tile * kPts;
         const int cnt = (int)min((int64_t)kPts, n - base);
         __syncthreads();  // previous tile's output stage is done with X
-        if (tid < kPts * 3) SX[tid] = (tid < cnt * 3) ? x[base * 3 + tid] : 0.0f;
+        if (net.emb_stride == 0 && tid < kPts * 3) SX[tid] = (tid < cnt * 3) ? x[base * 3 + tid] : 0.0f;
         __syncthreads();
 
         // ---------------- encode -> EMB[(e/4)][p][e%4] ------------------------------------
-        {
+        if (net.emb_stride > 0) {
+            load_emb_tile(EMB, x, net.emb_stride, base, cnt, E, net.emb_groups, kPts, kGroupFloats, tid, kThreadsSdf);
+        } else {
             const int p = tid & (kPts - 1);
             const int grp = tid >> 6;  // 0..7
             const float x0 = SX[p * 3], x1 = SX[p * 3 + 1], x2 = SX[p * 3 + 2];
@@ -362,11 +376,13 @@ __global__ __launch_bounds__(kThreads32, 2) void sdf_fwd_p32_kernel(HmLevels lv,
         const int64_t base = tile * kPts32;
         const int cnt = (int)min((int64_t)kPts32, n - base);
         __syncthreads();
-        if (tid < kPts32 * 3) SX[tid] = (tid < cnt * 3) ? x[base * 3 + tid] : 0.0f;
+        if (net.emb_stride == 0 && tid < kPts32 * 3) SX[tid] = (tid < cnt * 3) ? x[base * 3 + tid] : 0.0f;
         __syncthreads();
 
         // ---------------- encode -> EMB[(e/4)][p][e%4]: thread -> (point p, slot grp of 8) ----------------
-        {
+        if (net.emb_stride > 0) {
+            load_emb_tile(EMB, x, net.emb_stride, base, cnt, E, net.emb_groups, kPts32, kGroupFloats32, tid, kThreads32);
+        } else {
             const int p = tid & (kPts32 - 1);
             const int grp = tid >> 5;  // 0..7
             const float x0 = SX[p * 3], x1 = SX[p * 3 + 1], x2 = SX[p * 3 + 2];
@@ -582,11 +598,13 @@ __device__ __forceinline__ void sdf_m16_body(const HmLevels &lv, const SdfNet &n
         const int64_t base = tile * kPts16;
         const int cnt = (int)min((int64_t)kPts16, n - base);
         __syncthreads();
-        if (tid < kPts16 * 3) SX[tid] = (tid < cnt * 3) ? x[base * 3 + tid] : 0.0f;
+        if (net.emb_stride == 0 && tid < kPts16 * 3) SX[tid] = (tid < cnt * 3) ? x[base * 3 + tid] : 0.0f;
         __syncthreads();
 
         // ---- encode: thread -> (point p, slot c); 32 slots cover channels / levels
-        {
+        if (net.emb_stride > 0) {
+            load_emb_tile(EMB, x, net.emb_stride, base, cnt, E, emb_groups16, kPts16, kGroupFloats16, tid, kThreadsSdf);
+        } else {
             const int p = tid & (kPts16 - 1);
             const int c0 = tid >> 4;  // 0..31
             const float x0 = SX[p * 3], x1 = SX[p * 3 + 1], x2 = SX[p * 3 + 2];
@@ -825,11 +843,13 @@ __device__ __forceinline__ void sdf_m8_body(const HmLevels &lv, const SdfNet &ne
         const int64_t base = tile * PTS;
         const int cnt = (int)min((int64_t)PTS, n - base);
         __syncthreads();
-        if (tid < kPts8 * 3) SX[tid] = (tid < cnt * 3) ? x[base * 3 + tid] : 0.0f;
+        if (net.emb_stride == 0 && tid < kPts8 * 3) SX[tid] = (tid < cnt * 3) ? x[base * 3 + tid] : 0.0f;
         __syncthreads();
 
         // ---- encode: thread -> (point p, slot c0); 64 slots cover channels / levels
-        {
+        if (net.emb_stride > 0) {
+            load_emb_tile(EMB, x, net.emb_stride, base, cnt, E, emb_groups16, PTS, kGroupFloats8, tid, kThreadsSdf);
+        } else {
             const int p = tid & (kPts8 - 1);
             const int c0 = tid >> 3;  // 0..63
             const float x0 = SX[p * 3], x1 = SX[p * 3 + 1], x2 = SX[p * 3 + 2];
@@ -1071,20 +1091,44 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 
 extern "C" {
 
+static int sdf_fwd_impl(const HmLevels &lv, const hm_mlp_desc *mlp, const float *x, int64_t emb_stride, int64_t n,
+                        const float *table, const float *B_fourier, float *out, int64_t out_stride, int out_cols,
+                        int frac_mode, int tile_points, const int32_t *n_dev, int max_workgroups, void *stream);
+
 int hm_sdf_fwd(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *x, int64_t n, const float *table,
                const float *B_fourier, float *out, int64_t out_stride, int out_cols, int frac_mode, int tile_points,
                const int32_t *n_dev, int max_workgroups, void *stream) {
     HM_CHECK_ARG(desc && mlp, "hm_sdf_fwd: NULL descriptor");
+    HM_CHECK_ARG(n == 0 || (table && B_fourier), "hm_sdf_fwd: NULL pointer");
+    return sdf_fwd_impl(desc->lv, mlp, x, 0, n, table, B_fourier, out, out_stride, out_cols, frac_mode, tile_points,
+                        n_dev, max_workgroups, stream);
+}
+
+int hm_sdf_fwd_emb(const hm_mlp_desc *mlp, const float *emb, int64_t emb_stride, int emb_width, int64_t n, float *out,
+                   int64_t out_stride, int out_cols, int tile_points, const int32_t *n_dev, int max_workgroups,
+                   void *stream) {
+    HM_CHECK_ARG(mlp, "hm_sdf_fwd_emb: NULL descriptor");
+    HM_CHECK_ARG(emb_width >= 1 && emb_width <= 512 && emb_stride >= emb_width, "hm_sdf_fwd_emb: bad embedding width / stride");
+    HmLevels lv = {};
+    lv.L = 0; lv.F = 2; lv.E = emb_width;
+    return sdf_fwd_impl(lv, mlp, emb, emb_stride, n, nullptr, nullptr, out, out_stride, out_cols, HM_FRAC_REFERENCE,
+                        tile_points, n_dev, max_workgroups, stream);
+}
+
+static int sdf_fwd_impl(const HmLevels &lv, const hm_mlp_desc *mlp, const float *x, int64_t emb_stride, int64_t n,
+                        const float *table, const float *B_fourier, float *out, int64_t out_stride, int out_cols,
+                        int frac_mode, int tile_points, const int32_t *n_dev, int max_workgroups, void *stream) {
+    HM_CHECK_ARG(mlp, "hm_sdf_fwd: NULL descriptor");
     HM_CHECK_ARG(n >= 0, "hm_sdf_fwd: n < 0");
     HM_CHECK_ARG(frac_mode == HM_FRAC_REFERENCE || frac_mode == HM_FRAC_TRILINEAR, "hm_sdf_fwd: bad frac_mode");
     HM_CHECK_ARG(mlp->n_layers >= 1 && mlp->n_layers <= HM_MAX_LAYERS, "hm_sdf_fwd: n_layers out of range");
     HM_CHECK_ARG(tile_points == 0 || tile_points == 4 || tile_points == 8 || tile_points == 16 || tile_points == 32 ||
                      tile_points == 64,
                  "hm_sdf_fwd: tile_points must be 0, 4, 8, 16, 32 or 64");
-    const HmLevels &lv = desc->lv;
     SdfNet net;
     net.n_layers = mlp->n_layers;
     net.beta = mlp->beta;
+    net.emb_stride = emb_stride;
     const int emb_oct = (lv.E + 7) / 8;
     const int emb_b16 = (lv.E + 15) / 16;
     net.emb_groups = emb_oct * 2;
@@ -1124,7 +1168,7 @@ int hm_sdf_fwd(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *x,
     HM_CHECK_ARG((tile_points != 16 && tile_points != 8 && tile_points != 4) || have16,
                  "hm_sdf_fwd: tile_points 4 / 8 / 16 need w_packed_m16 in every layer");
     if (n == 0) return HM_OK;
-    HM_CHECK_ARG(x && table && B_fourier && out, "hm_sdf_fwd: NULL pointer");
+    HM_CHECK_ARG(x && out && (emb_stride > 0 || (table && B_fourier)), "hm_sdf_fwd: NULL pointer");
     // small batches: 16-point tiles spread the call over the whole chip (see sdf_m16_body / sdf_m8_body).
     // With a device-side count the host cannot know the batch size: both kernels are enqueued and
     // each returns at once unless the live count falls in its range.

@@ -370,11 +370,11 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Layout {
-    size_t off_f, off_i, off_b, off_pts, off_vals, off_cnt, total;
+    size_t off_f, off_i, off_b, off_pts, off_vals, off_cnt, off_emb, total;
     int64_t cap;
 };
 
-Layout make_layout(int64_t n, int n_steps) {
+Layout make_layout(int64_t n, int n_steps, int emb_width = 0) {
     Layout L;
     L.cap = n * (n_steps > 2 ? n_steps : 2);
     size_t o = 0;
@@ -384,6 +384,7 @@ Layout make_layout(int64_t n, int n_steps) {
     L.off_pts = o; o = align_up(o + sizeof(float) * 3 * (size_t)L.cap, 256);
     L.off_vals = o; o = align_up(o + sizeof(float) * (size_t)L.cap, 256);
     L.off_cnt = o; o = align_up(o + sizeof(int32_t) * C_COUNT, 256);
+    L.off_emb = o; o = align_up(o + sizeof(float) * (size_t)emb_width * (size_t)L.cap, 256);   // (filter-bank embedders)
     L.total = o;
     return L;
 }
@@ -397,12 +398,50 @@ int64_t hm_trace_workspace_bytes(int64_t n_rays, const hm_trace_cfg *cfg) {
     return (int64_t)make_layout(n_rays, cfg->n_steps).total;
 }
 
+int64_t hm_trace_workspace_bytes_nffb(int64_t n_rays, const hm_trace_cfg *cfg, int n_levels) {
+    if (n_rays < 0 || !cfg || cfg->n_steps < 1 || n_levels < 1 || n_levels > HM_MAX_LEVELS)
+        return hm_fail(HM_ERR_INVALID, "hm_trace_workspace_bytes_nffb: bad argument");
+    return (int64_t)make_layout(n_rays, cfg->n_steps, 3 + 8 + 8 * n_levels).total;
+}
+
+static int trace_forward_impl(const hm_grid_desc *desc, const hm_nffb_desc *nffb, const hm_mlp_desc *mlp,
+                              const float *table, const float *B_fourier, int frac_mode, int tile_points,
+                              const hm_trace_cfg *cfg, const float *cam_loc, const float *ray_dirs,
+                              const uint8_t *object_mask, const float *t_sphere, const uint8_t *hit_mask, int64_t n_rays,
+                              int64_t rays_per_image, const float *sampler_fracs, const float *steps_u,
+                              float *out_points, uint8_t *out_net_mask, float *out_dists, void *workspace,
+                              int64_t workspace_bytes, int32_t *stats_out, void *stream);
+
 int hm_trace_forward(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *table, const float *B_fourier,
                      int frac_mode, int tile_points, const hm_trace_cfg *cfg, const float *cam_loc,
                      const float *ray_dirs, const uint8_t *object_mask, const float *t_sphere,
                      const uint8_t *hit_mask, int64_t n_rays, int64_t rays_per_image, const float *sampler_fracs,
                      const float *steps_u, float *out_points, uint8_t *out_net_mask, float *out_dists,
                      void *workspace, int64_t workspace_bytes, int32_t *stats_out, void *stream) {
+    return trace_forward_impl(desc, nullptr, mlp, table, B_fourier, frac_mode, tile_points, cfg, cam_loc, ray_dirs,
+                              object_mask, t_sphere, hit_mask, n_rays, rays_per_image, sampler_fracs, steps_u, out_points,
+                              out_net_mask, out_dists, workspace, workspace_bytes, stats_out, stream);
+}
+
+int hm_trace_forward_nffb(const hm_grid_desc *desc, const hm_nffb_desc *nffb, const hm_mlp_desc *mlp, const float *table,
+                          const float *B_fourier, int frac_mode, int tile_points, const hm_trace_cfg *cfg,
+                          const float *cam_loc, const float *ray_dirs, const uint8_t *object_mask, const float *t_sphere,
+                          const uint8_t *hit_mask, int64_t n_rays, int64_t rays_per_image, const float *sampler_fracs,
+                          const float *steps_u, float *out_points, uint8_t *out_net_mask, float *out_dists,
+                          void *workspace, int64_t workspace_bytes, int32_t *stats_out, void *stream) {
+    HM_CHECK_ARG(nffb != nullptr, "hm_trace_forward_nffb: NULL embedder descriptor");
+    return trace_forward_impl(desc, nffb, mlp, table, B_fourier, frac_mode, tile_points, cfg, cam_loc, ray_dirs,
+                              object_mask, t_sphere, hit_mask, n_rays, rays_per_image, sampler_fracs, steps_u, out_points,
+                              out_net_mask, out_dists, workspace, workspace_bytes, stats_out, stream);
+}
+
+static int trace_forward_impl(const hm_grid_desc *desc, const hm_nffb_desc *nffb, const hm_mlp_desc *mlp,
+                              const float *table, const float *B_fourier, int frac_mode, int tile_points,
+                              const hm_trace_cfg *cfg, const float *cam_loc, const float *ray_dirs,
+                              const uint8_t *object_mask, const float *t_sphere, const uint8_t *hit_mask, int64_t n_rays,
+                              int64_t rays_per_image, const float *sampler_fracs, const float *steps_u,
+                              float *out_points, uint8_t *out_net_mask, float *out_dists, void *workspace,
+                              int64_t workspace_bytes, int32_t *stats_out, void *stream) {
     HM_CHECK_ARG(desc && mlp && cfg, "hm_trace_forward: NULL descriptor");
     HM_CHECK_ARG(n_rays >= 0 && rays_per_image >= 1, "hm_trace_forward: bad ray counts");
     HM_CHECK_ARG(cfg->n_steps >= 2 && cfg->n_steps <= 4096, "hm_trace_forward: n_steps out of range");
@@ -417,7 +456,8 @@ int hm_trace_forward(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const flo
                      out_points && out_net_mask && out_dists && workspace,
                  "hm_trace_forward: NULL pointer");
     HM_CHECK_ARG(!cfg->training || steps_u, "hm_trace_forward: training mode needs steps_u");
-    const Layout L = make_layout(n_rays, cfg->n_steps);
+    const int emb_width = nffb ? 3 + 8 + 8 * nffb->n_levels : 0;
+    const Layout L = make_layout(n_rays, cfg->n_steps, emb_width);
     HM_CHECK_ARG(workspace_bytes >= (int64_t)L.total, "hm_trace_forward: workspace too small");
     hipStream_t st = as_stream(stream);
     char *base = static_cast<char *>(workspace);
@@ -449,7 +489,15 @@ int hm_trace_forward(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const flo
     const unsigned g_rays = (unsigned)((n_rays + kTB - 1) / kTB);
     const unsigned g_samp = (unsigned)((n_rays * cfg->n_steps + kTB - 1) / kTB);
 
+    float *emb_ws = reinterpret_cast<float *>(base + L.off_emb);
     auto sdf = [&](int64_t capacity, const int32_t *n_dev) -> int {
+        if (nffb) {   // filter-bank embedder: its own fused kernel, then the MLP on the embedding rows
+            const int rc = hm_nffb_fwd(desc, nffb, a.w.pts, capacity, table, B_fourier, emb_ws, emb_width, frac_mode,
+                                       n_dev, stream);
+            if (rc != HM_OK) return rc;
+            return hm_sdf_fwd_emb(mlp, emb_ws, emb_width, emb_width, capacity, a.w.vals, 1, 1, tile_points, n_dev, 0,
+                                  stream);
+        }
         return hm_sdf_fwd(desc, mlp, a.w.pts, capacity, table, B_fourier, a.w.vals, 1, 1, frac_mode, tile_points, n_dev,
                           0, stream);
     };

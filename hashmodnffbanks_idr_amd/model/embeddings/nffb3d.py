@@ -8,9 +8,12 @@ Data flow (registry settings: PositionalEncodingNET, SIREN, has_out=False):
   .view does), each chunk goes through a NeRF positional encoding -> [N, W];
   after trunk layer l >= 1:  e = chunk_enc[l-1] (+ StyleAttention) + trunk ;  features += out_layer(e);
   output = [u, features / L].
-The hash-grid gather runs on the HIP encoder kernels, every Linear on the HIP fp32 MFMA GEMM
-(ops.linear, differentiable to any order); sin/cos/normalisation are elementwise torch expressions.
-A fused narrow-MLP kernel for this trunk is the next optimisation step.
+Two routes:
+  * no gradient needed (ray tracing, eval, plots): ONE fused kernel for the whole embedder - grid gather, positional
+    encodings, SIREN trunk, StyleAttention normalisation, shared out_layer, mean over levels (csrc/hm_nffb.hip via
+    ops.nffb_fwd; one thread per point, weights as scalar operands);
+  * gradient needed: hash-grid gather on the HIP encoder kernels, every Linear on the HIP fp32 MFMA GEMM (ops.linear,
+    differentiable to any order); sin/cos/normalisation are elementwise torch expressions.
 """
 import torch
 import torch.nn as nn
@@ -73,7 +76,17 @@ class FourierFilterBanks(nn.Module):
         for p in self.parameters():
             p.requires_grad = True
 
+    def __getstate__(self):   # the packed descriptor holds raw device pointers: never copied / pickled
+        d = self.__dict__.copy()
+        d.pop("_nffb_packed", None)
+        return d
+
+    def _needs_graph(self, input):
+        return torch.is_grad_enabled() and (input.requires_grad or any(p.requires_grad for p in self.parameters()))
+
     def forward(self, input: torch.Tensor, compute_grad=False) -> torch.Tensor:
+        if input.is_cuda and self.n_levels in (6, 8) and self.max_points_per_level == 2 and not self._needs_graph(input):
+            return ops.nffb_fwd(self, input.reshape(-1, self.num_inputs))
         x = input / self.bound
         u = (input + self.bound) / (2 * self.bound)
         grid = self.grid_enc(u)[..., x.shape[-1]:]

@@ -27,7 +27,7 @@ class StyleAttention(nn.Module):
         content_features = content.view(-1, self.d_in)
         style_features = style.view(-1, self.feature_vector_size)
         modulated = ops.linear(style_features, self.linear_transform.weight, self.linear_transform.bias)
-        attention_weights = F.softmax(F.linear(content_features, self.attention.weight, self.attention.bias), dim=1)
+        attention_weights = F.softmax(ops.linear(content_features, self.attention.weight, self.attention.bias), dim=1)
         weighted = attention_weights * modulated
         mean = weighted.mean(dim=1, keepdim=True)
         var = weighted.var(dim=1, unbiased=False, keepdim=True)

@@ -112,6 +112,14 @@ class ImplicitNetwork(nn.Module):
         emb = getattr(emb, "embedder_obj", None)
         return emb if isinstance(emb, MultiResHashGridMLP) else None
 
+    def _nffb_embedder(self):
+        """the FourierFilterBanks module ('FFB' / 'StyleModNFFB') when its fused kernel covers the configuration"""
+        emb = getattr(getattr(self, "embed_model", None), "embedder_obj", None)
+        if emb is not None and type(emb).__name__ == "FourierFilterBanks" and emb.n_levels in (6, 8) \
+                and emb.max_points_per_level == 2:
+            return emb
+        return None
+
     def _lin_params(self):
         ps = []
         for l in range(self.num_layers - 1):
@@ -121,6 +129,9 @@ class ImplicitNetwork(nn.Module):
 
     def _fusable(self):
         emb = self._hash_embedder()
+        if emb is None:
+            nf = self._nffb_embedder()
+            emb = nf.grid_enc if nf is not None else None
         if emb is None or not emb.table.is_cuda or emb.n_features != 2:
             return False
         widths = [getattr(self, "lin" + str(l)).bias.shape[0] for l in range(self.num_layers - 1)]
@@ -155,6 +166,9 @@ class ImplicitNetwork(nn.Module):
 
     def _fused(self, x, sdf_only):
         emb = self._hash_embedder()
+        if emb is None:     # filter-bank embedder: its own fused kernel, then the MLP kernel on the embedding rows
+            e = ops.nffb_fwd(self._nffb_embedder(), x)
+            return ops.sdf_fwd_emb(self.packed_weights(), e, sdf_only=sdf_only, tile_points=self.sdf_tile_points)
         return ops.sdf_fwd(emb.desc, self.packed_weights(), x, emb.table.detach(), emb.freq_encoding.B,
                            ops.FRAC_MODES[emb.frac_mode], sdf_only=sdf_only, tile_points=self.sdf_tile_points)
 

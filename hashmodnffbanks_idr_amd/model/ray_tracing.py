@@ -69,7 +69,8 @@ class RayTracing(nn.Module):
                                 float(self.line_search_step), int(self.line_step_iters),
                                 int(self.sphere_tracing_iters), int(self.n_steps), int(self.n_secant_steps),
                                 1 if self.training else 0)
-            need = ops.trace_workspace_bytes(N, cfg)
+            nf = net._nffb_embedder() if net._hash_embedder() is None else None
+            need = ops.trace_workspace_bytes(N, cfg, nf.n_levels if nf is not None else 0)
             if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
                 self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
             steps_u = None
@@ -79,14 +80,16 @@ class RayTracing(nn.Module):
                 else:
                     # same generator call as the reference (:277); it is made even when no ray ends up needing it
                     steps_u = torch.empty(self.n_steps).uniform_(0.0, 1.0).to(dev)
-            emb = net._hash_embedder()
+            emb = net._hash_embedder() if nf is None else nf.grid_enc
+            nffb = ops.nffb_packed(nf) if nf is not None else None
             stats = torch.zeros(16, dtype=torch.int32, device=dev)
             pts, mask, dists = ops.trace_forward(
                 emb.desc, net.packed_weights(), emb.table.detach(), emb.freq_encoding.B,
                 ops.FRAC_MODES[emb.frac_mode], net.sdf_tile_points, cfg, cam_loc.detach().contiguous().float(),
                 ray_directions.detach().reshape(N, 3).contiguous().float(),
                 object_mask.reshape(N).to(torch.uint8).contiguous(), t_sphere.reshape(N, 2).contiguous(),
-                hit.reshape(N).to(torch.uint8).contiguous(), P, self._linspace(dev), steps_u, self._ws, stats)
+                hit.reshape(N).to(torch.uint8).contiguous(), P, self._linspace(dev), steps_u, self._ws, stats,
+                nffb=nffb)
         self._stats = {"rays": N}
         self._stats_dev = stats
         return pts, mask.bool(), dists

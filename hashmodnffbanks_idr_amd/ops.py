@@ -415,27 +415,107 @@ def sdf_fwd(desc, packed, x, table, B, frac_mode=0, sdf_only=False, max_workgrou
     return out[:, 0] if sdf_only else out
 
 
+def sdf_fwd_emb(packed, emb, sdf_only=False, tile_points=0, n_dev=None, max_workgroups=0):
+    """The fused MLP + clamp on PRECOMPUTED embedding rows (hm_sdf_fwd_emb): SDF networks whose embedder is not
+    the plain hash grid (FourierFilterBanks via nffb_fwd)."""
+    require_gpu(emb)
+    if emb.stride(-1) != 1:
+        emb = emb.contiguous()
+    n, width = emb.shape
+    cols = 1 if sdf_only else packed.out_dim
+    out = torch.empty((n, cols), dtype=torch.float32, device=emb.device)
+    check(lib().hm_sdf_fwd_emb(C.byref(packed.desc), dptr(emb), emb.stride(0), width, n, dptr(out), cols, cols,
+                               int(tile_points), dptr(n_dev), int(max_workgroups), stream_ptr(emb)))
+    return out[:, 0] if sdf_only else out
+
+
+# =========================================================================================
+# fused Fourier-filter-bank embedder forward (csrc/hm_nffb.hip)
+# =========================================================================================
+class NffbPacked:
+    """[host] hm_nffb_desc over the live parameters of a FourierFilterBanks module (no copies: the kernel reads the
+    nn.Linear weights in place, so optimizer updates are seen without re-packing)."""
+
+    def __init__(self, mod):
+        self.desc = _lib.NffbDesc()
+        self.refresh(mod)
+
+    def refresh(self, mod):
+        d = self.desc
+        L = mod.n_levels
+        d.n_levels, d.bound, d.w0, d.style_eps = int(L), float(mod.bound), float(mod.sin_w0), 1e-5
+        keep = []
+        for l in range(L - 1):
+            lin = getattr(mod, "ff_lin" + str(l))
+            w, b = lin.weight.detach(), lin.bias.detach()
+            require_gpu(w, b)
+            if not (w.is_contiguous() and b.is_contiguous() and w.dtype == torch.float32):
+                raise ValueError("hashmod nffb: contiguous fp32 parameters expected")
+            d.trunk_w[l], d.trunk_b[l] = w.data_ptr(), b.data_ptr()
+            keep += [w, b]
+        d.out_w, d.out_b = mod.out_layer.weight.data_ptr(), mod.out_layer.bias.data_ptr()
+        if mod.modulationApplied:
+            lt = mod.StyleAttentionBlock.linear_transform
+            d.style_w, d.style_b = lt.weight.data_ptr(), lt.bias.data_ptr()
+            d.style_eps = float(mod.StyleAttentionBlock.eps)
+        else:
+            d.style_w, d.style_b = None, None
+        self.key = tuple(t.data_ptr() for t in keep)
+
+
+def nffb_packed(mod):
+    """the module's hm_nffb_desc, pointers refreshed (parameters may have been moved / re-bound since the last call)"""
+    pk = mod.__dict__.get("_nffb_packed")
+    if pk is None:
+        pk = mod.__dict__["_nffb_packed"] = NffbPacked(mod)
+    else:
+        pk.refresh(mod)
+    return pk
+
+
+def nffb_fwd(mod, x, n_dev=None, out=None):
+    """[N, 3 + 8 + 8L] embedding of a FourierFilterBanks module in one kernel (no autograd)."""
+    x = _prep_x(x)
+    grid = mod.grid_enc
+    require_gpu(x, grid.table)
+    n = x.shape[0]
+    width = mod.embeddings_dim
+    if out is None:
+        out = torch.empty((n, width), dtype=torch.float32, device=x.device)
+    pk = nffb_packed(mod)
+    check(lib().hm_nffb_fwd(grid.desc.handle, C.byref(pk.desc), dptr(x), n, dptr(grid.table.detach()),
+                            dptr(grid.freq_encoding.B), dptr(out), out.stride(0), FRAC_MODES[grid.frac_mode],
+                            dptr(n_dev), stream_ptr(x)))
+    return out
+
+
 # =========================================================================================
 # sync-free ray tracer (csrc/hm_trace.hip)
 # =========================================================================================
-def trace_workspace_bytes(n_rays, cfg):
+def trace_workspace_bytes(n_rays, cfg, nffb_levels=0):
+    if nffb_levels:
+        return check(lib().hm_trace_workspace_bytes_nffb(int(n_rays), C.byref(cfg), int(nffb_levels)))
     return check(lib().hm_trace_workspace_bytes(int(n_rays), C.byref(cfg)))
 
 
 def trace_forward(desc, packed, table, B, frac_mode, tile_points, cfg, cam_loc, ray_dirs, object_mask, t_sphere,
-                  hit_mask, rays_per_image, sampler_fracs, steps_u, workspace, stats=None):
-    """Enqueues the whole intersection search (no host sync).  Returns (points, net_mask_u8, dists)."""
+                  hit_mask, rays_per_image, sampler_fracs, steps_u, workspace, stats=None, nffb=None):
+    """Enqueues the whole intersection search (no host sync).  Returns (points, net_mask_u8, dists).
+    nffb: NffbPacked of a FourierFilterBanks embedder (desc / table / B are then its hash grid's)."""
     require_gpu(cam_loc, ray_dirs, object_mask, t_sphere, hit_mask, sampler_fracs, workspace)
     n = ray_dirs.shape[0]
     dev = ray_dirs.device
     pts = torch.empty((n, 3), dtype=torch.float32, device=dev)
     mask = torch.empty((n,), dtype=torch.uint8, device=dev)
     dists = torch.empty((n,), dtype=torch.float32, device=dev)
-    check(lib().hm_trace_forward(desc.handle, C.byref(packed.desc), dptr(table), dptr(B), int(frac_mode),
-                                 int(tile_points), C.byref(cfg), dptr(cam_loc), dptr(ray_dirs), dptr(object_mask),
-                                 dptr(t_sphere), dptr(hit_mask), n, int(rays_per_image), dptr(sampler_fracs),
-                                 dptr(steps_u), dptr(pts), dptr(mask), dptr(dists), dptr(workspace),
-                                 workspace.numel(), dptr(stats), stream_ptr(ray_dirs)))
+    tail = (dptr(table), dptr(B), int(frac_mode), int(tile_points), C.byref(cfg), dptr(cam_loc), dptr(ray_dirs),
+            dptr(object_mask), dptr(t_sphere), dptr(hit_mask), n, int(rays_per_image), dptr(sampler_fracs),
+            dptr(steps_u), dptr(pts), dptr(mask), dptr(dists), dptr(workspace), workspace.numel(), dptr(stats),
+            stream_ptr(ray_dirs))
+    if nffb is not None:
+        check(lib().hm_trace_forward_nffb(desc.handle, C.byref(nffb.desc), C.byref(packed.desc), *tail))
+    else:
+        check(lib().hm_trace_forward(desc.handle, C.byref(packed.desc), *tail))
     return pts, mask, dists
 
 

@@ -164,6 +164,36 @@ HM_API int hm_sdf_fwd(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const fl
                       const float *table, const float *B_fourier, float *out, int64_t out_stride, int out_cols,
                       int frac_mode, int tile_points, const int32_t *n_dev, int max_workgroups, void *stream);
 
+/* The same network evaluated on PRECOMPUTED embedding rows emb[i*emb_stride .. + emb_width) instead of encoding x in
+ * the kernel: the SDF network on top of an embedder other than the plain hash grid (FourierFilterBanks via
+ * hm_nffb_fwd; custom_embedder_decoder.py:147-164 + implicit_differentiable_renderer.py:96-113).  mlp's embedding
+ * segments must span ceil(emb_width/8) octets (ceil(emb_width/16) 16-blocks).                                    */
+HM_API int hm_sdf_fwd_emb(const hm_mlp_desc *mlp, const float *emb, int64_t emb_stride, int emb_width, int64_t n,
+                          float *out, int64_t out_stride, int out_cols, int tile_points, const int32_t *n_dev,
+                          int max_workgroups, void *stream);
+
+/* ---- Fourier-filter-bank embedders ('FFB', 'StyleModNFFB') forward, no grad ------------------------------------
+ * Replaces FourierFilterBanks.forward (model/embeddings/nffb3d.py:122-194, registry settings PositionalEncodingNET /
+ * SIREN / has_out=False) with PositionalEncoding (frequency_enc.py:6-51), Sine (Sine.py:5-25) and StyleAttention
+ * (style_Attention/styleMod.py:16-43) in ONE kernel:
+ *   out[i] = [ u(3) | mean over the L grid levels of out_layer(e_l) (W = 8 + 8L) ],  u = (x + bound) / (2 bound).
+ * desc: the embedder's own hash grid (n_levels == L in {6, 8}, F = 2); table / B_fourier as for hm_encode_fwd.
+ * trunk_w[0] [W,3], trunk_w[1..L-2] [W,W], trunk_b[l] [W]: ff_lin{l};  out_w [W,W], out_b [W]: out_layer;
+ * style_w / style_b: StyleAttention.linear_transform ([W,W], [W]) or both NULL for the plain 'FFB' embedder;
+ * w0 = L^F - L (Sine); style_eps = 1e-5.  All DEVICE pointers, row-major fp32.  hm_nffb_desc itself is [host].
+ * n_dev: optional device-side point count, as for hm_sdf_fwd.                                                   */
+typedef struct hm_nffb_desc {
+    int32_t n_levels;
+    float bound, w0, style_eps;
+    const float *trunk_w[HM_MAX_LEVELS];
+    const float *trunk_b[HM_MAX_LEVELS];
+    const float *out_w, *out_b;
+    const float *style_w, *style_b;
+} hm_nffb_desc;
+HM_API int hm_nffb_fwd(const hm_grid_desc *desc, const hm_nffb_desc *nf, const float *x, int64_t n, const float *table,
+                       const float *B_fourier, float *out, int64_t out_stride, int frac_mode, const int32_t *n_dev,
+                       void *stream);
+
 /* ---- ray / surface intersection search ------------------------------------------------------
  * Replaces RayTracing.forward and its helpers sphere_tracing / ray_sampler / secant /
  * minimal_sdf_points (model/ray_tracing.py:26-298) when the `sdf` callable is the network above:
@@ -201,6 +231,17 @@ HM_API int hm_trace_forward(const hm_grid_desc *desc, const hm_mlp_desc *mlp, co
                             const float *sampler_fracs, const float *steps_u, float *out_points,
                             uint8_t *out_net_mask, float *out_dists, void *workspace, int64_t workspace_bytes,
                             int32_t *stats_out, void *stream);
+
+/* The same search with the SDF network on a Fourier-filter-bank embedder (hm_nffb_fwd + hm_sdf_fwd_emb per round);
+ * desc / table / B_fourier are the embedder's own hash grid; workspace of hm_trace_workspace_bytes_nffb() bytes.     */
+HM_API int64_t hm_trace_workspace_bytes_nffb(int64_t n_rays, const hm_trace_cfg *cfg, int n_levels);
+HM_API int hm_trace_forward_nffb(const hm_grid_desc *desc, const hm_nffb_desc *nffb, const hm_mlp_desc *mlp,
+                                 const float *table, const float *B_fourier, int frac_mode, int tile_points,
+                                 const hm_trace_cfg *cfg, const float *cam_loc, const float *ray_dirs,
+                                 const uint8_t *object_mask, const float *t_sphere, const uint8_t *hit_mask,
+                                 int64_t n_rays, int64_t rays_per_image, const float *sampler_fracs,
+                                 const float *steps_u, float *out_points, uint8_t *out_net_mask, float *out_dists,
+                                 void *workspace, int64_t workspace_bytes, int32_t *stats_out, void *stream);
 
 /* ---- exact-fp32 GEMM (grad-enabled MLP path) ------------------------------------------------
  * Replaces the nn.Linear matmuls autograd runs for the SDF and rendering MLPs when gradients are

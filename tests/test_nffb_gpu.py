@@ -40,6 +40,29 @@ def test_embedder_forward_backward(golden, tag, et, L):
 
 
 @pytest.mark.parametrize("tag,et", [("ffb", "FFB"), ("stylemod", "StyleModNFFB")])
+@pytest.mark.parametrize("L", [6, 8])
+def test_fused_embedder_forward(golden, tag, et, L):
+    """The one-kernel no-grad route (csrc/hm_nffb.hip) against the reference fixture and against the layer-wise
+    autograd route of the same module; ragged sizes through the grid-stride loop."""
+    from hashmodnffbanks_idr_amd.model.custom_embedder_decoder import Custom_Embedding_Network
+    g = golden(f"nffb_{tag}_L{L}")
+    emb = _load(Custom_Embedding_Network(3, [3, 512], et, L, 5, 2, 16, 512, 1.0), g)
+    x = torch.from_numpy(g["x"].copy()).cuda()
+    with torch.no_grad():
+        y = emb(x)
+    err = np.abs(y.cpu().numpy() - g["out"]).max()
+    print(f"fused {et} L={L}: max |d| vs reference = {err:.3e}")
+    np.testing.assert_allclose(y.cpu().numpy(), g["out"], rtol=1e-4, atol=2e-5)
+    xr = (torch.rand(1000 + 37, 3, device="cuda") * 2.2 - 1.1)
+    with torch.no_grad():
+        yf = emb(xr)
+    ya = emb(xr.clone().requires_grad_(True)).detach()
+    np.testing.assert_allclose(yf.cpu().numpy(), ya.cpu().numpy(), rtol=1e-4, atol=2e-5)
+    with torch.no_grad():
+        assert emb(xr[:1]).shape == (1, 3 + 8 + 8 * L) and emb(xr[:0]).shape[0] == 0
+
+
+@pytest.mark.parametrize("tag,et", [("ffb", "FFB"), ("stylemod", "StyleModNFFB")])
 def test_sdf_network_on_nffb(golden, tag, et):
     from hashmodnffbanks_idr_amd.model.implicit_differentiable_renderer import ImplicitNetwork
     g = golden(f"nffb_sdf_{tag}")
@@ -69,3 +92,45 @@ def test_sdf_network_on_nffb(golden, tag, et):
             continue
         got = p.grad.double().norm().item()
         assert abs(got - ref) <= 5e-3 * ref + 1e-6, (k, got, ref)
+
+
+@pytest.mark.parametrize("tag,et", [("ffb", "FFB"), ("stylemod", "StyleModNFFB")])
+def test_fused_sdf_and_device_tracer_on_nffb(golden, tag, et):
+    """SDF network on a filter-bank embedder: (a) the fused no-grad route (hm_nffb_fwd + hm_sdf_fwd_emb, every tile
+    size) equals the layer-wise GEMM route; (b) the sync-free device tracer (hm_trace_forward_nffb) equals the generic
+    torch tracer bit for bit when both evaluate the SDF with the same tile size."""
+    import params as P
+    from hashmodnffbanks_idr_amd.model.implicit_differentiable_renderer import ImplicitNetwork
+    from hashmodnffbanks_idr_amd.model.ray_tracing import RayTracing
+    g = golden(f"nffb_sdf_{tag}")
+    net = ImplicitNetwork(16, 3, 1, [128] * 8, True, 0.6, [4], True, multires=6, embed_type=et, log2_max_hash_size=5,
+                          max_points_per_entry=2, base_resolution=16, desired_resolution=512, bound=1.0)
+    net = _load(net, g)
+    assert net._fusable() and net._hash_embedder() is None and net._nffb_embedder() is not None
+    x = (torch.rand(2500, 3, device="cuda") * 2 - 1)
+    with torch.enable_grad():
+        ref = net(x.clone().requires_grad_(True)).detach()
+    for tile in (0, 4, 8, 16, 64):
+        net.sdf_tile_points = tile
+        with torch.no_grad():
+            out, sdf = net(x), net.sdf(x)
+        np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(sdf.cpu().numpy(), ref[:, 0].cpu().numpy(), rtol=1e-4, atol=2e-5)
+    net.eval()
+    net.sdf_tile_points = 64
+    cam, dirs = P.make_rays(3, 300)
+    om = np.random.RandomState(3).uniform(0, 1, 300) < 0.7
+    outs = []
+    for dev_tracer in (True, False):
+        rt = RayTracing(1.0, 5.0e-5, 0.5, 3, 10, 100, 8).cuda()
+        rt.train(True)
+        rt.use_device_tracer = dev_tracer
+        rt.steps_override = torch.linspace(0.02, 0.97, 100)
+        with torch.no_grad():
+            outs.append(rt(sdf=net.sdf, cam_loc=torch.from_numpy(cam).cuda(), object_mask=torch.from_numpy(om).cuda(),
+                           ray_directions=torch.from_numpy(dirs).cuda()))
+        if dev_tracer:
+            st = rt.last_stats
+            assert st["unfinished"] == 0 and st["nonfinite"] == 0 and st["sdf_evals"] > 600
+    (p1, m1, d1), (p2, m2, d2) = outs
+    assert torch.equal(m1, m2) and torch.equal(d1, d2) and torch.equal(p1, p2)
