@@ -73,12 +73,19 @@ class Conf(dict):
 
 # measurement-only configurations (not golden-pinned): C2's level structure with every table L2-resident
 EXTRA_CONFIGS = {"C2_l2": (16, 15, 16, 512)}
+# BASELINE.json configs[2] / configs[4]: the filter-bank embedders with the shipped embedding_network block
+# (confs/embedder_conf_var/{FFB,StyleModNFFB}/dtu_fixed_cameras.conf: L=6, T=5, base 16, desired 512)
+NFFB_CONFIGS = {"C3": ("FFB", 6, 5, 16, 512, 4096), "C5": ("StyleModNFFB", 6, 5, 16, 512, 2048)}
 
 
 def idr_conf(cfg):
     """confs/embedder_conf_var/MultiResHashPointsAndViewDirs/dtu_fixed_cameras.conf with the
     embedding_network block of BASELINE.json's config."""
-    L, T, b, d = P.CONFIGS[cfg] if cfg in P.CONFIGS else EXTRA_CONFIGS[cfg]
+    embed_type = "HashGrid"
+    if cfg in NFFB_CONFIGS:
+        embed_type, L, T, b, d, _ = NFFB_CONFIGS[cfg]
+    else:
+        L, T, b, d = P.CONFIGS[cfg] if cfg in P.CONFIGS else EXTRA_CONFIGS[cfg]
     return Conf(
         feature_vector_size=256,
         implicit_network=dict(d_in=3, d_out=1, dims=[512] * 8, geometric_init=True, bias=0.6, skip_in=[4],
@@ -87,7 +94,7 @@ def idr_conf(cfg):
                                weight_norm=True, multires_view=4),
         ray_tracer=dict(object_bounding_sphere=1.0, sdf_threshold=5.0e-5, line_search_step=0.5, line_step_iters=3,
                         sphere_tracing_iters=10, n_steps=100, n_secant_steps=8),
-        embedding_network=dict(embed_type="HashGrid", log2_max_hash_size=T, max_points_per_entry=2,
+        embedding_network=dict(embed_type=embed_type, log2_max_hash_size=T, max_points_per_entry=2,
                                base_resolution=b, desired_resolution=d, bound=1.0),
     )
 
@@ -215,6 +222,36 @@ def mlp_roofline(net, log2_n=18, iters=5, warmup=2):
             "frac": round(tf / MFMA_F32_PEAK_TF, 4), "traffic": None, "kernel": "sdf_fwd_kernel",
             "units_per_launch": n, "flop_per_unit": flops, "avg_launch_ms": round(avg_ms, 4),
             "points_per_s": round(n / (avg_ms * 1e-3), 1)}
+
+
+def mlp_bf16_roofline(net, log2_n=18, iters=5, warmup=2):
+    """bf16 coarse-search variant of the fused SDF kernel: same flop count, dense bf16 MFMA peak (2.5 PFLOP/s)."""
+    from hashmodnffbanks_idr_amd import ops
+    dev = next(net.parameters()).device
+    n = 1 << log2_n
+    g = torch.Generator(device="cpu").manual_seed(99)
+    x = (torch.rand((n, 3), generator=g) * 2 - 1).to(dev)
+    net.bf16_coarse_search = True
+    emb = net._hash_embedder()
+    pk = net.packed_weights()
+    run = lambda: ops.sdf_fwd_bf16(emb.desc, pk, x, emb.table.detach(), emb.freq_encoding.B)   # noqa: E731
+    for _ in range(warmup):
+        run()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for s, e in evs:
+        s.record()
+        run()
+        e.record()
+    torch.cuda.synchronize()
+    ms = np.asarray([s.elapsed_time(e) for s, e in evs])
+    avg_ms = float(ms.mean())
+    flops = 2.0 * (SDF_MAC_PER_POINT - 512 * 256)
+    tf = n * flops / (avg_ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(tf, 2), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
+            "traffic": None, "kernel": "sdf_fwd_bf16_kernel", "units_per_launch": n, "flop_per_unit": flops,
+            "avg_launch_ms": round(avg_ms, 4), "points_per_s": round(n / (avg_ms * 1e-3), 1),
+            "note": "bound by the per-CU weight stream (1 KB of bf16 weights per 6 MFMAs), not by the matrix pipe"}
 
 
 def cpu_baseline(model, n_rays=256, reps=2):
@@ -355,7 +392,9 @@ def main():
                     help="fixed = section-8(d) workload (weights stay at geometric init; the headline); train = lr 1e-4")
     ap.add_argument("--gather-log2n", type=int, default=22)
     ap.add_argument("--calib", default="1,0", help="gather_calib: lanes per 128-B block, byte stride between them")
-    ap.add_argument("--only", choices=["gather", "gather_bwd", "mlp", "gather_calib"], default=None,
+    ap.add_argument("--bf16", type=int, default=-1,
+                    help="1: the ray tracer's coarse scans on the bf16 kernel (default for --cfg C5 = BASELINE configs[4])")
+    ap.add_argument("--only", choices=["gather", "gather_bwd", "mlp", "mlp_bf16", "gather_calib"], default=None,
                     help="profiling helper: run just one kernel section on cuda:0 and print its object")
     ap.add_argument("--cfg", default=None,
                     help="hash-grid config (tests/golden/params.py): default C2 = BASELINE configs[1]; C4 = configs[3] "
@@ -386,6 +425,8 @@ def main():
             print(json.dumps(gather_roofline(emb, args.gather_log2n)))
         elif args.only == "gather_bwd":
             print(json.dumps(gather_bwd_roofline(emb, args.gather_log2n)))
+        elif args.only == "mlp_bf16":
+            print(json.dumps(mlp_bf16_roofline(model.implicit_network)))
         else:
             print(json.dumps(mlp_roofline(model.implicit_network)))
         return
@@ -401,7 +442,13 @@ def main():
     torch.cuda.set_device(device)
     loss_fn = IDRLoss(eikonal_weight=0.1, mask_weight=100.0, alpha=50.0)
     inp, gt = synthetic_batch(1234 + rank, args.rays, device)
-    L, T = P.CONFIGS[cfg][0], P.CONFIGS[cfg][1]
+    if cfg in NFFB_CONFIGS:
+        L, T = NFFB_CONFIGS[cfg][1], NFFB_CONFIGS[cfg][2]
+        if args.rays == RAYS_PER_GPU:
+            args.rays = NFFB_CONFIGS[cfg][5]
+            inp, gt = synthetic_batch(1234 + rank, args.rays, device)
+    else:
+        L, T = P.CONFIGS[cfg][0], P.CONFIGS[cfg][1]
 
     def make_opt(model, lr):
         # dense Adam over ALL parameters incl. the hash table (reference: idr_train.py:127-128)
@@ -410,12 +457,14 @@ def main():
         from hashmodnffbanks_idr_amd.training.optim import ClipAdam   # clip_grad_norm_(1.0) + Adam in three launches
         return ClipAdam(model.parameters(), lr=lr, max_norm=1.0)
 
+    use_bf16 = (args.bf16 == 1) or (args.bf16 < 0 and cfg == "C5")
     legs = {}
     model = None
     for leg, lr in (("fixed", 0.0), ("train", 1.0e-4)):
         if args.legs not in ("both", leg):
             continue
         model = _build(cfg, device, lr)
+        model.implicit_network.bf16_coarse_search = use_bf16
         reducer = parallel.GradAllReducer(model.parameters()) if world > 1 else None
         torch.manual_seed(100 + rank)  # per-rank eikonal points / step fractions
         dt, stats, final_loss, mode = _run_leg(args, model, make_opt(model, lr), loss_fn, reducer, inp, gt, world,
@@ -434,9 +483,13 @@ def main():
             "metric": "rays/sec fwd+bwd (hash+SDF MLP)", "value": head["value"], "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"DTU-shaped synthetic uniform-sphere rays, MultiResHash L={L} T=2^{T} F=2 "
-                                   f"(BASELINE.json configs[{3 if cfg == 'C4' else 1}]), full IDR training step "
+            "vs_baseline": None, "data": "synthetic",
+            "dtype": "bf16 (ray-search coarse scans on v_mfma_f32_32x32x16_bf16, fp32 accumulate; sphere tracing, secant "
+                     "refinement and every grad-enabled evaluation f32)" if use_bf16 else "f32",
+            "config": {"workload": f"DTU-shaped synthetic uniform-sphere rays, "
+                                   + (f"{NFFB_CONFIGS[cfg][0]} embedder over a hash grid " if cfg in NFFB_CONFIGS else "MultiResHash ")
+                                   + f"L={L} T=2^{T} F=2 "
+                                   f"(BASELINE.json configs[{ {'C4': 3, 'C3': 2, 'C5': 4}.get(cfg, 1) }]), full IDR training step "
                                    "(forward + IDRLoss + backward + clip + Adam)"
                                    + (", weights held at the geometric initialisation (lr = 0): the SURVEY.md 8(d) workload"
                                       if "fixed" in legs else ", lr 1e-4 (surface moves during the timed region)"),
@@ -447,7 +500,9 @@ def main():
         }
         if "fixed" in legs and "train" in legs:
             line["train_leg"] = legs["train"]
-        if not args.no_extras:
+        if not args.no_extras and cfg in NFFB_CONFIGS:
+            line["cpu_baseline"] = None      # (the torch-CPU port covers the hash-grid embedder only)
+        elif not args.no_extras:
             emb = head_model.implicit_network.embed_model.embedder_obj
             line["roofline"] = gather_roofline(emb, args.gather_log2n)
             line["roofline_bwd"] = gather_bwd_roofline(emb, args.gather_log2n, iters=5, warmup=2)

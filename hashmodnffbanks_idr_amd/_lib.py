@@ -40,6 +40,9 @@ SIGNATURES = {
     "hm_trace_workspace_bytes_nffb": (_i64, [_i64, _p, _int]),
     "hm_trace_forward_nffb": (_int, [_p, _p, _p, _p, _p, _int, _int, _p, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _p,
                                      _p, _p, _i64, _p, _p]),
+    "hm_pack_mlp_layer_bf16": (_int, [_p, _i64, _int, _int, _int, _p, _p]),
+    "hm_sdf_fwd_bf16": (_int, [_p, _p, _p, _i64, _p, _p, _p, _i64, _int, _p, _i64, _p]),
+    "hm_sdf_fwd_emb_bf16": (_int, [_p, _p, _i64, _int, _i64, _p, _i64, _p, _i64, _p]),
     "hm_pack_mlp_layer": (_int, [_p, _i64, _p, _int, _int, _int, _p, _p, _p, _p]),
     "hm_softplus": (_int, [_int, _p, _p, _p, _p, _p, _i64, C.c_float, C.c_float, _p]),
     "hm_sdf_head": (_int, [_int, _p, _i64, _i64, C.c_float, _p, _p, _p, _p, _p, _p]),
@@ -57,7 +60,8 @@ SIGNATURES = {
 class MlpLayer(C.Structure):
     _fields_ = [("w_packed", C.c_void_p), ("bias", C.c_void_p), ("out_dim", C.c_int32), ("n_tiles", C.c_int32),
                 ("seg_octets", C.c_int32 * 2), ("seg_src", C.c_int32 * 2), ("activation", C.c_int32),
-                ("post_div_sqrt2", C.c_int32), ("w_packed_m16", C.c_void_p), ("seg_blocks16", C.c_int32 * 2)]
+                ("post_div_sqrt2", C.c_int32), ("w_packed_m16", C.c_void_p), ("seg_blocks16", C.c_int32 * 2),
+                ("w_packed_bf16", C.c_void_p)]
 
 
 class GemmEpilogue(C.Structure):
@@ -75,7 +79,7 @@ class AdamTensor(C.Structure):
 class TraceCfg(C.Structure):
     _fields_ = [("object_bounding_sphere", C.c_float), ("sdf_threshold", C.c_float), ("line_search_step", C.c_double),
                 ("line_step_iters", C.c_int32), ("sphere_tracing_iters", C.c_int32), ("n_steps", C.c_int32),
-                ("n_secant_steps", C.c_int32), ("training", C.c_int32)]
+                ("n_secant_steps", C.c_int32), ("training", C.c_int32), ("coarse_bf16", C.c_int32)]
 
 
 class NffbDesc(C.Structure):

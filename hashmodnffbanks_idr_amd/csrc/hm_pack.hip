@@ -48,9 +48,39 @@ __global__ __launch_bounds__(256) void pack_layer_kernel(PackArgs a) {
     }
 }
 
+// bf16 operand image for v_mfma_f32_32x32x16_bf16 (hm_sdf_bf16.hip): same K space as the 16-k image,
+//   w_bf16[((u*nb + t)*64 + l)*8 + j] = bf16(W[32u + (l&31)][16t + 8(l>>5) + j]),  u < n_tiles, t < nb
+__global__ __launch_bounds__(256) void pack_layer_bf16_kernel(PackArgs a, __bf16 *img) {
+    const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)a.n_tiles * a.nb * 512;
+    if (d >= total) return;
+    const int jj = d & 7, l = (d >> 3) & 63;
+    const int64_t blk = d >> 9;
+    const int t = (int)(blk % a.nb), u = (int)(blk / a.nb);
+    img[d] = (__bf16)fetch(a, 32 * u + (l & 31), 16 * t + 8 * (l >> 5) + jj, a.p16_0);   // round to nearest even
+}
+
 }  // namespace
 
 extern "C" {
+
+int hm_pack_mlp_layer_bf16(const float *W, int64_t ldw, int out_dim, int seg_width0, int seg_width1, void *w_packed_bf16,
+                           void *stream) {
+    HM_CHECK_ARG(W && w_packed_bf16, "hm_pack_mlp_layer_bf16: NULL pointer");
+    HM_CHECK_ARG(out_dim >= 1 && seg_width0 >= 1 && seg_width1 >= 0 && ldw >= seg_width0 + seg_width1,
+                 "hm_pack_mlp_layer_bf16: bad shape");
+    PackArgs a = {};
+    a.W = W; a.ldw = ldw; a.out_dim = out_dim;
+    a.n_tiles = (out_dim + 31) / 32;
+    a.w0 = seg_width0; a.w1 = seg_width1;
+    a.p16_0 = (seg_width0 + 15) / 16 * 16;
+    a.nb = a.p16_0 / 16 + (seg_width1 + 15) / 16;
+    const int64_t total = (int64_t)a.n_tiles * a.nb * 512;
+    hipLaunchKernelGGL(pack_layer_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), a, static_cast<__bf16 *>(w_packed_bf16));
+    HM_CHECK_LAUNCH("hm_pack_mlp_layer_bf16");
+    return HM_OK;
+}
 
 int hm_pack_mlp_layer(const float *W, int64_t ldw, const float *bias, int out_dim, int seg_width0, int seg_width1,
                       float *w_packed, float *w_packed_m16, float *bias_padded, void *stream) {

@@ -1,0 +1,59 @@
+// hm_sdf_common.h - device helpers shared by the fused SDF kernels (hm_sdf.hip: exact fp32; hm_sdf_bf16.hip: bf16
+// coarse-search variant).  Included inside each file's anonymous namespace.
+#pragma once
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+
+struct SdfNet {  // by value -> kernarg
+    int32_t n_layers;
+    int32_t x_groups;    // k-groups (of 4) in the X region
+    int32_t emb_groups;  // k-groups in the EMB region
+    float beta;          // Laplace density beta = |beta_param| + beta_min
+    int64_t emb_stride;  // > 0: `x` holds PRECOMPUTED embedding rows (emb_stride floats apart, lv.E used) - the encode
+                         //      phase becomes a tile load (embedders other than the plain hash grid, hm_sdf_fwd_emb)
+    hm_mlp_layer layer[HM_MAX_LAYERS];
+};
+
+// tile of precomputed embedding rows -> EMB[(e/4)][p][e%4] (group stride gf floats), zero padded to 4*egroups columns
+__device__ __forceinline__ void load_emb_tile(float *EMB, const float *__restrict__ emb, int64_t stride, int64_t base,
+                                              int cnt, int E, int egroups, int pts, int gf, int tid, int nthreads) {
+    const int epad = egroups * 4;
+    for (int i = tid; i < pts * epad; i += nthreads) {
+        const int p = i / epad, e = i - p * epad;
+        EMB[(e >> 2) * gf + p * 4 + (e & 3)] = (p < cnt && e < E) ? emb[(base + p) * stride + e] : 0.0f;
+    }
+}
+
+// nn.Softplus(beta=100, threshold=20): y = x if 100x > 20 else log1p(exp(100x))/100
+// evaluated as max(z,0) + ln(1 + 2^(-|z| log2 e)) with the native exp2/log2 units (abs error < 1e-7
+// before the /100), 8 VALU instructions instead of two libm calls.
+__device__ __forceinline__ float softplus100(float a) {
+    const float z = a * 100.0f;
+    const float t = __builtin_amdgcn_exp2f(-fabsf(z) * 1.4426950408889634f);
+    const float l = __builtin_amdgcn_logf(1.0f + t) * 0.6931471805599453f;  // v_log_f32 is log2
+    const float sp = (fmaxf(z, 0.0f) + l) / 100.0f;
+    return z > 20.0f ? a : sp;
+}
+
+// density_net.py:20-30 + implicit_differentiable_renderer.py:112
+__device__ __forceinline__ float sdf_clamp(float s, float beta) {
+    const float alpha = 1.0f / beta;
+    const float sg = (s > 0.0f) ? 1.0f : ((s < 0.0f) ? -1.0f : 0.0f);
+    const float rho = alpha * (0.5f + 0.5f * sg * expm1f(-fabsf(s) / beta));
+    return tanhf(s / (2.0f + rho));
+}
+
+template <int FRAC>
+__device__ __forceinline__ void corner(float x, int32_t res, int bit, uint32_t &u, float &w) {
+    const float xs = __fmul_rn(x, (float)res);
+    if (FRAC == HM_FRAC_REFERENCE) {
+        u = (uint32_t)((int32_t)xs) + (uint32_t)bit;
+        w = bit ? 0.0f : 1.0f;
+    } else {
+        const float fl = floorf(xs);
+        const float xf = __fsub_rn(xs, fl);
+        u = (uint32_t)((int32_t)fl) + (uint32_t)bit;
+        w = bit ? xf : __fsub_rn(1.0f, xf);
+    }
+}
+

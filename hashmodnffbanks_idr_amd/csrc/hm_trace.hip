@@ -524,7 +524,23 @@ static int trace_forward_impl(const hm_grid_desc *desc, const hm_nffb_desc *nffb
         hipLaunchKernelGGL(ray_samples_kernel, dim3(g_samp), dim3(kTB), 0, st, a, a.w.list_sel, (int)C_NSEL,
                            (int)C_NSEL_PTS, a.w.t_min, a.w.t_max, steps_u, (int)C_NSAMP_PTS);
     {
-        int rc = sdf(n_rays * cfg->n_steps, a.w.cnt + C_BIG_PTS);
+        const int64_t capacity = n_rays * cfg->n_steps;
+        const int32_t *n_big = a.w.cnt + C_BIG_PTS;
+        int rc;
+        if (!cfg->coarse_bf16) {
+            rc = sdf(capacity, n_big);
+        } else if (nffb) {   // coarse scans in bf16 above 8192 live points, exact fp32 small tiles below
+            rc = hm_nffb_fwd(desc, nffb, a.w.pts, capacity, table, B_fourier, emb_ws, emb_width, frac_mode, n_big, stream);
+            if (rc == HM_OK)
+                rc = hm_sdf_fwd_emb(mlp, emb_ws, emb_width, emb_width, capacity, a.w.vals, 1, 1, -1, n_big, 0, stream);
+            if (rc == HM_OK)
+                rc = hm_sdf_fwd_emb_bf16(mlp, emb_ws, emb_width, emb_width, capacity, a.w.vals, 1, n_big, 8193, stream);
+        } else {
+            rc = hm_sdf_fwd(desc, mlp, a.w.pts, capacity, table, B_fourier, a.w.vals, 1, 1, frac_mode, -1, n_big, 0, stream);
+            if (rc == HM_OK)
+                rc = hm_sdf_fwd_bf16(desc, mlp, a.w.pts, capacity, table, B_fourier, a.w.vals, 1, frac_mode, n_big, 8193,
+                                     stream);
+        }
         if (rc != HM_OK) return rc;
     }
     if (cfg->training) hipLaunchKernelGGL(closest_reduce_kernel, dim3(g_rays), dim3(kTB), 0, st, a);

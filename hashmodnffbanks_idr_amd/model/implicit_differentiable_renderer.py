@@ -100,6 +100,10 @@ class ImplicitNetwork(nn.Module):
         self._force_repack = False
         self._fold_cache = None
         self.sdf_tile_points = 0  # fused kernel tile: 0 auto (16-point tiles for small batches), 16, 64
+        # BASELINE configs[4] ("bf16"): the ray tracer's coarse scans (100-sample sign-change search, closest approach)
+        # run on the bf16 MFMA variant of the fused kernel; sphere tracing, secant refinement and every grad-enabled
+        # evaluation stay exact fp32.  Off by default: the reference has no reduced-precision behaviour.
+        self.bf16_coarse_search = False
 
     def __getstate__(self):  # the packed-weight cache holds raw device pointers: never copied / pickled
         d = self.__dict__.copy()
@@ -143,13 +147,16 @@ class ImplicitNetwork(nn.Module):
         # _version does not see writes through raw pointers (training.optim.ClipAdam, graph replays): those bump
         # _lib.param_epoch(), which is part of the key
         key = (_lib.param_epoch(),) + tuple((p.data_ptr(), p._version) for p in ps)
-        if self._packed is None or key != self._packed_key or self._force_repack:
+        if self._packed is None or key != self._packed_key or self._force_repack or \
+                self._packed.has_bf16 != bool(self.bf16_coarse_search):
             self._force_repack = False
             with torch.no_grad():
                 Ws = [_folded_weight(getattr(self, "lin" + str(l))) for l in range(self.num_layers - 1)]
                 bs = [getattr(self, "lin" + str(l)).bias for l in range(self.num_layers - 1)]
-                if self._packed is None or self._packed.bufs[0][0].device != Ws[0].device:
-                    self._packed = ops.PackedSdf(Ws, bs, self.dims[0], self.skip_in, self._beta_value())
+                if self._packed is None or self._packed.bufs[0][0].device != Ws[0].device or \
+                        self._packed.has_bf16 != bool(self.bf16_coarse_search):
+                    self._packed = ops.PackedSdf(Ws, bs, self.dims[0], self.skip_in, self._beta_value(),
+                                                 with_bf16=bool(self.bf16_coarse_search))
                 else:
                     self._packed.update(Ws, bs, self._beta_value())
             self._packed_key = key

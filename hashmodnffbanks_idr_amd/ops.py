@@ -348,8 +348,10 @@ class PackedSdf:
     The image buffers are allocated once (stable pointers, so the descriptor stays valid across
     optimizer steps and inside captured graphs); update() re-packs them with one kernel per layer."""
 
-    def __init__(self, weights, biases, E, skip_in, beta):
+    def __init__(self, weights, biases, E, skip_in, beta, with_bf16=False):
         n = len(weights)
+        self.has_bf16 = bool(with_bf16)
+        self.bf16 = []
         self.desc = _lib.MlpDesc()
         self.desc.n_layers = n
         self.keep, self.segs, self.bufs = [], [], []
@@ -374,6 +376,12 @@ class PackedSdf:
             self.segs.append((out_dim, w0, w1))
             ly = self.desc.layer[l]
             ly.w_packed, ly.bias, ly.w_packed_m16 = img8.data_ptr(), bpad.data_ptr(), img16.data_ptr()
+            if with_bf16:    # operand image of hm_sdf_fwd_bf16 (2-byte elements; torch.bfloat16 as the container)
+                ib = torch.empty(n_tiles * (b0 + b1) * 512, dtype=torch.bfloat16, device=dev)
+                self.bf16.append(ib)
+                ly.w_packed_bf16 = ib.data_ptr()
+            else:
+                ly.w_packed_bf16 = None
             ly.out_dim, ly.n_tiles = out_dim, n_tiles
             ly.seg_octets[0], ly.seg_octets[1] = oct0, oct1
             ly.seg_blocks16[0], ly.seg_blocks16[1] = b0, b1
@@ -398,6 +406,9 @@ class PackedSdf:
             self.keep = [W, b]
             check(lib().hm_pack_mlp_layer(dptr(W), W.stride(0), dptr(b), out_dim, w0, w1, dptr(img8), dptr(img16),
                                           dptr(bpad), stream_ptr(W)))
+            if self.has_bf16:
+                check(lib().hm_pack_mlp_layer_bf16(dptr(W), W.stride(0), out_dim, w0, w1, dptr(self.bf16[l]),
+                                                   stream_ptr(W)))
 
 
 def sdf_fwd(desc, packed, x, table, B, frac_mode=0, sdf_only=False, max_workgroups=0, tile_points=0, n_dev=None):
@@ -413,6 +424,30 @@ def sdf_fwd(desc, packed, x, table, B, frac_mode=0, sdf_only=False, max_workgrou
                            dptr(out), cols, cols, int(frac_mode), int(tile_points), dptr(n_dev),
                            int(max_workgroups), stream_ptr(x)))
     return out[:, 0] if sdf_only else out
+
+
+def sdf_fwd_bf16(desc, packed, x, table, B, frac_mode=0, n_dev=None, run_min=0):
+    """sdf-only values [N] from the bf16 variant of the fused kernel (hm_sdf_fwd_bf16; coarse-search precision)."""
+    x = _prep_x(x)
+    require_gpu(x, table, B)
+    if not packed.has_bf16:
+        raise ValueError("hashmod sdf_fwd_bf16: the packed weights carry no bf16 image")
+    n = x.shape[0]
+    out = torch.empty((n, 1), dtype=torch.float32, device=x.device)
+    check(lib().hm_sdf_fwd_bf16(desc.handle, C.byref(packed.desc), dptr(x), n, dptr(table), dptr(B.contiguous()),
+                                dptr(out), 1, int(frac_mode), dptr(n_dev), int(run_min), stream_ptr(x)))
+    return out[:, 0]
+
+
+def sdf_fwd_emb_bf16(packed, emb, n_dev=None, run_min=0):
+    require_gpu(emb)
+    if emb.stride(-1) != 1:
+        emb = emb.contiguous()
+    n, width = emb.shape
+    out = torch.empty((n, 1), dtype=torch.float32, device=emb.device)
+    check(lib().hm_sdf_fwd_emb_bf16(C.byref(packed.desc), dptr(emb), emb.stride(0), width, n, dptr(out), 1,
+                                    dptr(n_dev), int(run_min), stream_ptr(emb)))
+    return out[:, 0]
 
 
 def sdf_fwd_emb(packed, emb, sdf_only=False, tile_points=0, n_dev=None, max_workgroups=0):

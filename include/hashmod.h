@@ -138,6 +138,9 @@ typedef struct hm_mlp_layer {
      * w_packed_m16[((u*nb + t)*64 + l)*4 + e] = W[16u + (l&15)][16t + 4(l>>4) + e],  u < 2*n_tiles. */
     const float *w_packed_m16;
     int32_t seg_blocks16[2];
+    /* optional bf16 image for hm_sdf_fwd_bf16 (NULL = not provided): same K space as the 16-k image,
+     * w_packed_bf16[((u*nb + t)*64 + l)*8 + j] = bf16(W[32u + (l&31)][16t + 8(l>>5) + j]),  u < n_tiles (2-byte elements). */
+    const void *w_packed_bf16;
 } hm_mlp_layer;
 
 typedef struct hm_mlp_desc {
@@ -153,16 +156,33 @@ HM_API int hm_pack_mlp_layer(const float *W, int64_t ldw, const float *bias, int
                              int seg_width1, float *w_packed, float *w_packed_m16, float *bias_padded,
                              void *stream);
 
+HM_API int hm_pack_mlp_layer_bf16(const float *W, int64_t ldw, int out_dim, int seg_width0, int seg_width1,
+                                  void *w_packed_bf16, void *stream);
+
 /* x [n,3] -> out.  out_cols == 1: only the clamped sdf, out[i*out_stride];  out_cols == last
  * layer's out_dim: the whole [sdf | feature vector] row.
  * tile_points: 32 (two 4-wave workgroups per CU: throughput), 64 (one 8-wave workgroup per CU), 16 (small batches),
- * 8 or 4 (<= 2048 / 1024 points: bound by the weight stream alone), 0 = choose by n (on the device when n_dev is given).
+ * 8 or 4 (<= 2048 / 1024 points: bound by the weight stream alone), 0 = choose by n (on the device when n_dev is given),
+ * -1 = like 0 but ONLY for n <= 8192 (larger batches are left to another launch, e.g. hm_sdf_fwd_bf16 with run_min 8193).
  * n_dev: optional DEVICE int32; when non-NULL the kernel evaluates min(n, *n_dev) points, so a
  *        caller that compacts work on the device needs no host synchronisation (n is the capacity).
  * max_workgroups <= 0: fill the chip once (persistent grid-stride over tiles).                    */
 HM_API int hm_sdf_fwd(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *x, int64_t n,
                       const float *table, const float *B_fourier, float *out, int64_t out_stride, int out_cols,
                       int frac_mode, int tile_points, const int32_t *n_dev, int max_workgroups, void *stream);
+
+/* bf16 variant (BASELINE configs[4]), sdf-only output out[i*out_stride]: hidden-layer weights and activations in bf16
+ * on v_mfma_f32_32x32x16_bf16 (fp32 accumulate); the embedding, every product that consumes it (layer 0, the skip
+ * segment), bias / Softplus, the last layer and the clamp stay fp32.  Meant for the tracer's coarse scans (sign-change
+ * sampler, closest approach); runs only when the live point count is >= run_min (pair it with hm_sdf_fwd(tile_points
+ * = -1) for the small counts).  Needs w_packed, bias and w_packed_bf16 in every layer.  hm_sdf_fwd_emb_bf16: the same
+ * on precomputed embedding rows.  No reference behaviour exists for reduced precision: the error against
+ * hm_sdf_fwd and the loss-curve criterion are measured in tests/test_bf16_gpu.py.                                      */
+HM_API int hm_sdf_fwd_bf16(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *x, int64_t n,
+                           const float *table, const float *B_fourier, float *out, int64_t out_stride, int frac_mode,
+                           const int32_t *n_dev, int64_t run_min, void *stream);
+HM_API int hm_sdf_fwd_emb_bf16(const hm_mlp_desc *mlp, const float *emb, int64_t emb_stride, int emb_width, int64_t n,
+                               float *out, int64_t out_stride, const int32_t *n_dev, int64_t run_min, void *stream);
 
 /* The same network evaluated on PRECOMPUTED embedding rows emb[i*emb_stride .. + emb_width) instead of encoding x in
  * the kernel: the SDF network on top of an embedder other than the plain hash grid (FourierFilterBanks via
@@ -221,6 +241,8 @@ typedef struct hm_trace_cfg {
     int32_t n_steps;
     int32_t n_secant_steps;
     int32_t training;
+    int32_t coarse_bf16;           /* != 0: the sampler / closest-approach scans run on hm_sdf_fwd_bf16 (needs w_packed_bf16);
+                                      sphere tracing and the secant refinement stay on the exact-fp32 kernels */
 } hm_trace_cfg;
 
 HM_API int64_t hm_trace_workspace_bytes(int64_t n_rays, const hm_trace_cfg *cfg);
