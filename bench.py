@@ -326,6 +326,27 @@ def _build(cfg, device, lr):
     return model
 
 
+def _side_leg(cfg, device, bf16, steps=6, warmup=3):
+    """short fixed-weights leg of another BASELINE configuration on rank 0 (reported beside the headline)"""
+    import types
+    from hashmodnffbanks_idr_amd.model.loss import IDRLoss
+    from hashmodnffbanks_idr_amd.training.optim import ClipAdam
+    rays = NFFB_CONFIGS[cfg][5]
+    a = types.SimpleNamespace(no_graph=False, warmup=warmup, steps=steps, rays=rays)
+    model = _build(cfg, device, 0.0)
+    model.implicit_network.bf16_coarse_search = bool(bf16)
+    inp, gt = synthetic_batch(1234, rays, device)
+    torch.manual_seed(100)
+    dt, stats, final_loss, mode = _run_leg(a, model, ClipAdam(model.parameters(), lr=0.0, max_norm=1.0),
+                                           IDRLoss(eikonal_weight=0.1, mask_weight=100.0, alpha=50.0), None, inp, gt, 1,
+                                           device, 0)
+    et, L, T = NFFB_CONFIGS[cfg][0], NFFB_CONFIGS[cfg][1], NFFB_CONFIGS[cfg][2]
+    return {"value": round(rays * steps / dt, 1), "unit": "rays/s", "ms_per_step": round(dt / steps * 1e3, 3),
+            "steps": steps, "rays": rays, "workload": f"{et} embedder L={L} T=2^{T} F=2, {rays} rays, weights at init (lr = 0)",
+            "dtype": "bf16 coarse ray-search scans, f32 elsewhere" if bf16 else "f32",
+            "sdf_evals_per_step": stats, "step": mode}
+
+
 def _run_leg(args, model, opt, loss_fn, reducer, inp, gt, world, device, rank):
     """W untimed warm-up steps, then EXACTLY K timed steps between barrier + synchronize; max over ranks."""
     from hashmodnffbanks_idr_amd import parallel
@@ -465,7 +486,18 @@ def main():
             continue
         model = _build(cfg, device, lr)
         model.implicit_network.bf16_coarse_search = use_bf16
-        reducer = parallel.GradAllReducer(model.parameters()) if world > 1 else None
+        reducer = None
+        if world > 1:
+            # hash-table gradients travel as (point, feature-gradient) pairs (parallel.PointGradExchange, ~0.7 MB per
+            # rank instead of 40 / 224 MB dense) in the static graph step; HM_DP_SPARSE=0 or --no-graph: dense all-reduce
+            exchanges = []
+            if not args.no_graph and os.environ.get("HM_DP_SPARSE", "1") != "0":
+                for net in (model.implicit_network, model.rendering_network):
+                    emb = getattr(getattr(net, "embed_model", None), "embedder_obj", None)
+                    emb = getattr(emb, "grid_enc", emb)          # filter-bank embedders own a hash grid too
+                    if emb is not None and hasattr(emb, "grad_collector"):
+                        exchanges.append(parallel.PointGradExchange(emb))
+            reducer = parallel.GradAllReducer(model.parameters(), sparse=exchanges)
         torch.manual_seed(100 + rank)  # per-rank eikonal points / step fractions
         dt, stats, final_loss, mode = _run_leg(args, model, make_opt(model, lr), loss_fn, reducer, inp, gt, world,
                                                device, rank)
@@ -514,7 +546,11 @@ def main():
                 emb4 = MultiResHashGridMLP(True, 3, Lc, 2, Tc, bc, dc).to(device)
                 line["roofline_c4"] = gather_roofline(emb4, args.gather_log2n)
                 del emb4
+            line["roofline_mlp_bf16"] = mlp_bf16_roofline(_build(cfg, device, 0.0).implicit_network)
             line["cpu_baseline"] = cpu_baseline(head_model)
+            if world == 1:     # BASELINE configs[2] and [4] (filter-bank embedders), short legs beside the headline
+                line["config3_leg"] = _side_leg("C3", device, False)
+                line["config5_leg"] = _side_leg("C5", device, True)
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -568,6 +568,60 @@ __global__ __launch_bounds__(kThreads) void encode_bwd_table_kernel(HmLevels lv,
     for (int f = 0; f < F; ++f) atomicAdd(row + f, __fmul_rn(w, g[f]));
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Deterministic table gradient (no atomics): contributions are keyed by their destination row, sorted by the caller
+// (any stable sort; torch.sort in ops.encode_bwd_table), and every run of equal keys is summed by ONE thread in
+// sorted order and added to the table with a plain read-modify-write (each row has exactly one owner).  Bitwise
+// reproducible for a given contribution order - what keeps data-parallel replicas identical when every rank builds
+// its dense gradient from the same all-gathered contributions (parallel.PointGradExchange).
+template <int FRAC>
+__global__ __launch_bounds__(kThreads) void encode_rows_kernel(HmLevels lv, const float *__restrict__ x, int64_t n,
+                                                               int32_t *__restrict__ keys,
+                                                               float *__restrict__ wts) {
+    constexpr int C = FRAC == HM_FRAC_REFERENCE ? 1 : 8;   // reference mode: only corner 0 carries weight
+    const int L = lv.L;
+    const int64_t gid = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (gid >= n * L * C) return;
+    const int c = (int)(gid % C);
+    const int64_t pl = gid / C;
+    const int64_t i = pl / L;
+    const int l = (int)(pl - i * L);
+    uint32_t u[3];
+    float w = 1.0f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float wd;
+        voxel_and_weight<FRAC>(x[i * 3 + d], lv.res[l], (c >> d) & 1, u[d], wd);
+        w = __fmul_rn(w, wd);
+    }
+    keys[gid] = (int32_t)(lv.row_off[l] + hm_mod_rows(hm_hash3(u[0], u[1], u[2]), lv.rows[l], lv.magic[l]));
+    if (wts) wts[gid] = w;
+}
+
+__global__ __launch_bounds__(kThreads) void segment_scatter_kernel(const int32_t *__restrict__ keys,
+                                                                   const int64_t *__restrict__ perm, int64_t K, int L,
+                                                                   int F, int C, const float *__restrict__ d_feat,
+                                                                   int64_t d_feat_stride, const float *__restrict__ wts,
+                                                                   float *__restrict__ d_table) {
+    const int64_t k = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (k >= K) return;
+    const int32_t key = keys[k];
+    if (k > 0 && keys[k - 1] == key) return;      // not the first contribution of its row
+    float acc[8];
+    for (int f = 0; f < F; ++f) acc[f] = 0.0f;
+    for (int64_t m = k; m < K && keys[m] == key; ++m) {
+        const int64_t jx = perm[m];
+        const int64_t pl = jx / C;
+        const int64_t i = pl / L;
+        const int l = (int)(pl - i * L);
+        const float w = wts ? wts[jx] : 1.0f;
+        const float *g = d_feat + i * d_feat_stride + l * F;
+        for (int f = 0; f < F; ++f) acc[f] = __fadd_rn(acc[f], __fmul_rn(w, g[f]));
+    }
+    float *row = d_table + (int64_t)key * F;
+    for (int f = 0; f < F; ++f) row[f] = __fadd_rn(row[f], acc[f]);
+}
+
 // Counter calibration for 8-byte row gathers (diagnostic; bench.py --only gather_calib).  Every group of `group`
 // consecutive lanes reads 8-byte rows of ONE pseudo-random 128-B-aligned block of a table far larger than the
 // Infinity Cache, lane g of the group at byte offset g * stride_bytes inside the block: the ALGORITHMIC bytes and the
@@ -592,6 +646,43 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 }  // namespace
 
 extern "C" {
+
+int hm_encode_rows(const hm_grid_desc *desc, const float *x, int64_t n, int frac_mode, int32_t *keys_out,
+                   float *weights_out, void *stream) {
+    HM_CHECK_ARG(desc != nullptr && n >= 0, "hm_encode_rows: bad argument");
+    HM_CHECK_ARG(frac_mode == HM_FRAC_REFERENCE || frac_mode == HM_FRAC_TRILINEAR, "hm_encode_rows: bad frac_mode");
+    HM_CHECK_ARG(desc->total_rows < ((uint64_t)1 << 31), "hm_encode_rows: table too large for 32-bit row keys");
+    if (n == 0) return HM_OK;
+    HM_CHECK_ARG(x && keys_out, "hm_encode_rows: NULL pointer");
+    const int C = frac_mode == HM_FRAC_REFERENCE ? 1 : 8;
+    HM_CHECK_ARG(C == 1 || weights_out, "hm_encode_rows: trilinear mode needs the weight output");
+    const int64_t total = n * desc->lv.L * C;
+    const int64_t grid = (total + kThreads - 1) / kThreads;
+    HM_CHECK_ARG(grid <= 0x7fffffffLL, "hm_encode_rows: n too large for one launch");
+    if (frac_mode == HM_FRAC_REFERENCE)
+        hipLaunchKernelGGL(encode_rows_kernel<HM_FRAC_REFERENCE>, dim3((unsigned)grid), dim3(kThreads), 0,
+                           as_stream(stream), desc->lv, x, n, keys_out, weights_out);
+    else
+        hipLaunchKernelGGL(encode_rows_kernel<HM_FRAC_TRILINEAR>, dim3((unsigned)grid), dim3(kThreads), 0,
+                           as_stream(stream), desc->lv, x, n, keys_out, weights_out);
+    HM_CHECK_LAUNCH("hm_encode_rows");
+    return HM_OK;
+}
+
+int hm_encode_bwd_table_sorted(const hm_grid_desc *desc, const int32_t *keys_sorted, const int64_t *perm, int64_t n_keys,
+                               int corners, const float *d_feat, int64_t d_feat_stride, const float *weights,
+                               float *d_table, void *stream) {
+    HM_CHECK_ARG(desc != nullptr && n_keys >= 0 && (corners == 1 || corners == 8), "hm_encode_bwd_table_sorted: bad argument");
+    HM_CHECK_ARG(d_feat_stride >= desc->lv.L * desc->lv.F && desc->lv.F <= 8, "hm_encode_bwd_table_sorted: bad stride / F");
+    if (n_keys == 0) return HM_OK;
+    HM_CHECK_ARG(keys_sorted && perm && d_feat && d_table, "hm_encode_bwd_table_sorted: NULL pointer");
+    const int64_t grid = (n_keys + kThreads - 1) / kThreads;
+    HM_CHECK_ARG(grid <= 0x7fffffffLL, "hm_encode_bwd_table_sorted: too many contributions for one launch");
+    hipLaunchKernelGGL(segment_scatter_kernel, dim3((unsigned)grid), dim3(kThreads), 0, as_stream(stream), keys_sorted,
+                       perm, n_keys, desc->lv.L, desc->lv.F, corners, d_feat, d_feat_stride, weights, d_table);
+    HM_CHECK_LAUNCH("hm_encode_bwd_table_sorted");
+    return HM_OK;
+}
 
 int hm_diag_gather_calib(const float *table, int64_t table_bytes, int64_t n, int group, int stride_bytes, float *out,
                          void *stream) {

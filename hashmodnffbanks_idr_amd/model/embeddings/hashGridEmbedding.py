@@ -71,6 +71,7 @@ class MultiResHashGridMLP(nn.Module):
         self.table = nn.Parameter(torch.cat(chunks, 0).to(DEVICE))
         self.freq_encoding = self.freq_encoding.to(DEVICE)
         self.embeddings_dim = in_dim + n_levels * max_points_per_level + (self.freq_encoding.embeddings_dim - in_dim)
+        self.grad_collector = None   # parallel.PointGradExchange when the table gradient is exchanged sparsely
         self._register_state_dict_hook(MultiResHashGridMLP._split_table_hook)
         self._register_load_state_dict_pre_hook(self._fuse_table_hook)
 
@@ -111,9 +112,14 @@ class MultiResHashGridMLP(nn.Module):
             out = ops.encode_fwd(self.desc, x2, self.table, B, fm)
         elif not x2.requires_grad:
             # only the table needs a gradient: one fused kernel, backward = table scatter
-            out = ops.encode_table_grad(x2, self.table, B, self.desc, fm)
+            out = ops.encode_table_grad(x2, self.table, B, self.desc, fm, self.grad_collector)
         else:
             four = self.freq_encoding(x2.float())
-            feat = ops.hash_features(x2, self.table, self.desc, fm)
+            # reference frac mode: d(hash features)/dx is identically 0 (hashGridEmbedding.py:86), so the node is kept
+            # OFF the x-graph: autograd.grad(e, x, create_graph=True) in ImplicitNetwork.gradient would otherwise run
+            # this node's table backward (a dense scatter that is then thrown away - a custom Function cannot see
+            # that only d/dx was asked for), and a sparse gradient collector would record a bogus contribution
+            xh = x2.detach() if self.frac_mode == "reference" else x2
+            feat = ops.hash_features(xh, self.table, self.desc, fm, self.grad_collector)
             out = torch.cat([four, feat], dim=-1)
         return out.reshape(*lead, self.embeddings_dim)

@@ -102,8 +102,10 @@ def encode_fwd(desc, x, table, B, frac_mode=0, hash_only=False):
     return out
 
 
-def encode_bwd_table(desc, x, d_feat, frac_mode=0, out=None):
-    """Scatter-add of the hash-feature gradient d_feat [N,L*F] into a [rows,F] table gradient."""
+def encode_bwd_table(desc, x, d_feat, frac_mode=0, out=None, deterministic=False):
+    """Scatter-add of the hash-feature gradient d_feat [N,L*F] into a [rows,F] table gradient.
+    deterministic: sort the contributions by destination row (torch.sort, stable) and sum each row's run in one thread
+    (hm_encode_rows + hm_encode_bwd_table_sorted) instead of fp32 atomics - bitwise reproducible."""
     x = _prep_x(x)
     require_gpu(x, d_feat)
     n = x.shape[0]
@@ -112,6 +114,15 @@ def encode_bwd_table(desc, x, d_feat, frac_mode=0, out=None):
         d_feat = d_feat.contiguous()
     if out is None:
         out = torch.zeros((desc.total_rows, desc.F), dtype=torch.float32, device=x.device)
+    if deterministic and n > 0:
+        corners = 1 if int(frac_mode) == 0 else 8
+        keys = torch.empty(n * desc.L * corners, dtype=torch.int32, device=x.device)
+        wts = torch.empty(n * desc.L * corners, dtype=torch.float32, device=x.device) if corners == 8 else None
+        check(lib().hm_encode_rows(desc.handle, dptr(x), n, int(frac_mode), dptr(keys), dptr(wts), stream_ptr(x)))
+        skeys, perm = torch.sort(keys, stable=True)
+        check(lib().hm_encode_bwd_table_sorted(desc.handle, dptr(skeys), dptr(perm), keys.numel(), corners, dptr(d_feat),
+                                               d_feat.stride(0), dptr(wts), dptr(out), stream_ptr(x)))
+        return out
     check(lib().hm_encode_bwd_table(desc.handle, dptr(x), n, dptr(d_feat), d_feat.stride(0), dptr(out),
                                     int(frac_mode), stream_ptr(x)))
     return out
@@ -125,8 +136,8 @@ class _HashFeatures(torch.autograd.Function):
     xf = x - x.float() kills the interpolation weights (hashGridEmbedding.py:86)."""
 
     @staticmethod
-    def forward(ctx, x, table, B, desc, frac_mode):
-        ctx.desc, ctx.frac_mode = desc, frac_mode
+    def forward(ctx, x, table, B, desc, frac_mode, collector=None):
+        ctx.desc, ctx.frac_mode, ctx.collector = desc, frac_mode, collector
         ctx.hoff = 0 if B is None else 3 + 2 * desc.L
         ctx.save_for_backward(x)
         return encode_fwd(desc, x, table, B, frac_mode, hash_only=B is None)
@@ -137,13 +148,19 @@ class _HashFeatures(torch.autograd.Function):
         d_table = None
         if ctx.needs_input_grad[1]:
             d_feat = d_out[:, ctx.hoff:] if ctx.hoff else d_out
-            d_table = _HashScatter.apply(x, d_feat, ctx.desc, ctx.frac_mode)
+            if ctx.collector is not None and ctx.collector.active:
+                # data-parallel run with the sparse exchange (parallel.PointGradExchange): the contribution stays
+                # (points, feature gradients); the dense table gradient is formed once, from ALL ranks' contributions
+                ctx.collector.add(x, d_feat)
+                d_table = None
+            else:
+                d_table = _HashScatter.apply(x, d_feat, ctx.desc, ctx.frac_mode)
         if ctx.needs_input_grad[0]:
             if ctx.hoff:
                 raise RuntimeError("internal: full-row encode node must not be used when x requires grad")
             if ctx.frac_mode != 0:
                 raise NotImplementedError("frac_mode='trilinear' has no d/dx kernel yet (non-parity mode)")
-        return None, d_table, None, None, None
+        return None, d_table, None, None, None, None
 
 
 class _HashScatter(torch.autograd.Function):
@@ -160,18 +177,18 @@ class _HashScatter(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         gg = None
         if ctx.needs_input_grad[1]:
-            gg = _HashFeatures.apply(x, gg_table.contiguous(), None, ctx.desc, ctx.frac_mode)
+            gg = _HashFeatures.apply(x, gg_table.contiguous(), None, ctx.desc, ctx.frac_mode, None)
         return None, gg, None, None
 
 
-def hash_features(x, table, desc, frac_mode=0):
+def hash_features(x, table, desc, frac_mode=0, collector=None):
     """[N,L*F] hash features with autograd (table grads of any order)."""
-    return _HashFeatures.apply(_prep_x(x), table, None, desc, frac_mode)
+    return _HashFeatures.apply(_prep_x(x), table, None, desc, frac_mode, collector)
 
 
-def encode_table_grad(x, table, B, desc, frac_mode=0):
+def encode_table_grad(x, table, B, desc, frac_mode=0, collector=None):
     """Full [N,E] embedding in ONE kernel, differentiable w.r.t. the table only (x is a constant)."""
-    return _HashFeatures.apply(_prep_x(x).detach(), table, B, desc, frac_mode)
+    return _HashFeatures.apply(_prep_x(x).detach(), table, B, desc, frac_mode, collector)
 
 
 # =========================================================================================

@@ -6,9 +6,18 @@ per step, issued after backward and before clip_grad_norm_ / Adam (idr_train.py:
 With equal shards the mean of the per-rank gradients equals the gradient of the reference's
 global loss (rgb / mask terms are sum/N, the eikonal term is a mean; loss.py:18,38,47).
 
-Buckets are sized for xGMI (point-to-point, per-link bound): the hash-table gradient
-(39.8 MiB at T=2^19, 223.5 MiB at T=2^22) is reduced in place as one large message; all MLP
-gradients (~12 MiB) travel as one flat bucket.  Both collectives are issued asynchronously.
+Buckets are sized for xGMI (point-to-point, per-link bound): all MLP gradients (~12 MiB) travel as one flat
+bucket.  The hash-table gradient (39.8 MiB at T=2^19, 223.5 MiB at T=2^22) has two routes:
+  * dense: reduced in place as one large message (always available);
+  * sparse (static / graph-captured steps): a step touches <= 0.4 % of the rows, and a rank's whole table gradient
+    is determined by the few thousand (point, feature-gradient) pairs its backward scattered.  Those pairs
+    (PointGradExchange, ~0.7 MB per rank) are all-gathered instead, and every rank scatters ALL ranks' pairs into
+    its own dense gradient with the ordinary table-backward kernel.  RowValueExchange is the same exchange for
+    (row id, value) pairs (generic, CPU-capable).  The result equals the dense mean up to the order of the fp32
+    additions (tests/test_distributed_cpu.py, tests/test_distributed_gpu.py).
+Why not "overlap the table all-reduce with backward": the embedding is the FIRST layer, so its gradient is the LAST
+thing backward produces - there is nothing left to overlap with, and clip_grad_norm_ needs every gradient before
+the first Adam update.  Shrinking the message (sparse route) is what removes the cost.
 Works unchanged with the gloo backend on CPU tensors (tests).
 """
 import os
@@ -48,11 +57,118 @@ def shard_rays(model_input, ground_truth, rank, world):
     return mi, gt
 
 
-class GradAllReducer:
-    """Mean all-reduce of every gradient: big tensors in place, the rest through one flat bucket."""
+class _SparseExchange:
+    """Common part of the sparse gradient exchanges: a fixed-capacity payload [cap, width] per rank (rows beyond the
+    step's contributions stay zero and add nothing), all-gathered, then applied by every rank to a STATIC dense
+    gradient tensor that is (re)attached to the parameter - so a captured optimizer graph keeps reading one address."""
 
-    def __init__(self, params, big_numel=1 << 20):
-        self.params = [p for p in params if p.requires_grad]
+    def __init__(self, param, width):
+        self.param, self.width = param, width
+        self.active = True
+        self.payload = None          # [cap, width], allocated by the first step
+        self.cursor = 0
+        self.dense = None            # static dense gradient of `param`
+        self._gathered = None
+
+    def begin_step(self):
+        self.cursor = 0
+
+    def _rows(self, n):
+        """rows [cursor, cursor+n) of the payload (grown only while no capacity has been fixed by an exchange)"""
+        dev = self.param.device
+        if self.payload is None or self.cursor + n > self.payload.shape[0]:
+            if self._gathered is not None:
+                raise RuntimeError("sparse gradient exchange: more contributions than the fixed capacity "
+                                   "(the step is not static)")
+            new = torch.zeros((max(2 * (self.cursor + n), 1024), self.width), dtype=torch.float32, device=dev)
+            if self.payload is not None and self.cursor:
+                new[:self.cursor].copy_(self.payload[:self.cursor])
+            self.payload = new
+        view = self.payload[self.cursor:self.cursor + n]
+        self.cursor += n
+        return view
+
+    def exchange(self, world):
+        if self.payload is None:
+            self.payload = torch.zeros((1024, self.width), dtype=torch.float32, device=self.param.device)
+        if self.cursor < self.payload.shape[0]:
+            self.payload[self.cursor:].zero_()          # stale rows of an earlier, larger step must add nothing
+        cap = self.payload.shape[0]
+        if self._gathered is None or self._gathered.shape[0] != world * cap:
+            caps = torch.tensor([cap], device=self.param.device, dtype=torch.int64)
+            lo, hi = caps.clone(), caps.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            if int(lo) != int(hi):
+                raise RuntimeError("sparse gradient exchange: ranks disagree on the payload capacity")
+            self._gathered = torch.empty((world * cap, self.width), dtype=torch.float32, device=self.param.device)
+        dist.all_gather(list(self._gathered.split(cap, 0)), self.payload)
+        if self.dense is None or self.dense.shape != self.param.shape or self.dense.device != self.param.device:
+            self.dense = torch.zeros_like(self.param)
+        else:
+            self.dense.zero_()
+        self.apply(self._gathered, self.dense)
+        self.dense.mul_(1.0 / world)
+        self.param.grad = self.dense
+
+    def attach(self):
+        """parameter.grad = the static dense tensor (after zero_grad(set_to_none=True), before a graph capture)"""
+        if self.dense is None:
+            self.dense = torch.zeros_like(self.param)
+        self.param.grad = self.dense
+
+
+class RowValueExchange(_SparseExchange):
+    """(row id, value) pairs of a [rows, F] parameter: payload row = [row id as float64-safe int in fp32 pairs, F values].
+    Row ids are split into two fp32-exact halves (hi = id // 65536, lo = id % 65536) so the payload stays one fp32
+    tensor for a single collective."""
+
+    def __init__(self, param):
+        super().__init__(param, 2 + param.shape[1])
+
+    def add(self, rows, values):
+        view = self._rows(rows.shape[0])
+        view[:, 0] = (rows // 65536).to(torch.float32)
+        view[:, 1] = (rows % 65536).to(torch.float32)
+        view[:, 2:] = values
+
+    def apply(self, gathered, dense):
+        rows = gathered[:, 0].to(torch.int64) * 65536 + gathered[:, 1].to(torch.int64)
+        dense.index_add_(0, rows, gathered[:, 2:])      # zero-valued padding rows add nothing (row 0)
+
+
+class PointGradExchange(_SparseExchange):
+    """The product's route for a MultiResHashGridMLP table: payload row = [x(3) | d_feat(L*F)], i.e. exactly the inputs
+    of the table-backward kernel (hm_encode_bwd_table).  Registered as ``emb.grad_collector``; the encoder's autograd
+    node hands its contributions to add() instead of scattering them (ops._HashFeatures.backward)."""
+
+    def __init__(self, emb):
+        super().__init__(emb.table, 3 + emb.n_levels * emb.n_features)
+        self.emb = emb
+        emb.grad_collector = self
+
+    def add(self, x, d_feat):
+        from . import ops
+        view = self._rows(x.shape[0])
+        ops.dcopy_(view[:, 0:3], x.detach().reshape(-1, 3))
+        ops.dcopy_(view[:, 3:], d_feat.detach() if d_feat.stride(-1) == 1 else d_feat.detach().contiguous())
+
+    def apply(self, gathered, dense):
+        from . import ops
+        # deterministic scatter: every rank sums the SAME gathered contributions in the SAME order, so the replicas'
+        # tables stay bitwise identical (fp32 atomics would let them drift apart by ulps per step)
+        ops.encode_bwd_table(self.emb.desc, gathered[:, 0:3].contiguous(), gathered[:, 3:],
+                             ops.FRAC_MODES[self.emb.frac_mode], out=dense, deterministic=True)
+
+
+class GradAllReducer:
+    """Mean all-reduce of every gradient: big tensors in place, the rest through one flat bucket; parameters
+    listed in `sparse` (exchange objects) take the sparse route instead."""
+
+    def __init__(self, params, big_numel=1 << 20, sparse=()):
+        self.sparse = list(sparse)
+        skip = {id(ex.param) for ex in self.sparse}
+        self.params = [p for p in params if p.requires_grad and id(p) not in skip]
         self.big_numel = big_numel
         self.assume_dense = False   # set by GraphedTrainStep once the iteration is a replayed static graph
         self.frozen_grads = False   # set with it: the captured optimizer graph reads THESE .grad tensors; never rebind
@@ -65,6 +181,8 @@ class GradAllReducer:
             return
         world = dist.get_world_size()
         dev = self.params[0].device
+        for ex in self.sparse:
+            ex.exchange(world)
         # a parameter may have no gradient on one rank only (e.g. no surface hit in its shard): agree first
         if self.assume_dense and all(p.grad is not None for p in self.params):
             have = [1] * len(self.params)      # replayed static iteration: every rank has every gradient, no handshake

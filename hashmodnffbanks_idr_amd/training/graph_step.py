@@ -60,7 +60,12 @@ class GraphedTrainStep:
         eik.uniform_(-bb, bb)
         return steps, eik, ev
 
+    def _sparse(self):
+        return getattr(self.reducer, "sparse", ()) if self.reducer is not None else ()
+
     def _fwd_bwd(self):
+        for ex in self._sparse():
+            ex.begin_step()
         s = self.static
         out = self.model.forward_static(s["input"], s["eik"], s["steps"])
         lo = idr_loss_terms(out, s["rgb"], self.loss_fn.eikonal_weight, self.loss_fn.mask_weight, self.loss_fn.alpha)
@@ -123,6 +128,8 @@ class GraphedTrainStep:
             # capture (records the kernels, does not run them), then fall through to the first replay
             self.model.implicit_network._force_repack = True  # make the capture contain the weight re-pack
             self.opt.zero_grad(set_to_none=True)
+            for ex in self._sparse():      # their dense gradients are static tensors the optimizer graph reads
+                ex.attach()
             torch.cuda.synchronize()
             # with RCCL alive its watchdog thread polls events; only this thread's calls must obey capture rules
             mode = "thread_local" if (torch.distributed.is_available() and torch.distributed.is_initialized()) else "global"

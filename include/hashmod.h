@@ -107,6 +107,19 @@ HM_API int hm_encode_fwd_ws(const hm_grid_desc *desc, const float *x, int64_t n,
 HM_API int hm_encode_bwd_table(const hm_grid_desc *desc, const float *x, int64_t n, const float *d_feat,
                         int64_t d_feat_stride, float *d_table, int frac_mode, void *stream);
 
+/* Deterministic form of the same gradient (no atomics).  hm_encode_rows lists, for every (point, level[, corner]),
+ * the destination row in the fused table (keys_out [n*L*C] int32, C = 1 in reference frac mode - only corner 0 carries
+ * weight - and 8 in trilinear mode, where weights_out [n*L*C] receives the interpolation weights).  The caller sorts
+ * the keys with ANY stable sort (perm = the sorting permutation, int64); hm_encode_bwd_table_sorted then sums each run
+ * of equal keys in sorted order in one thread and adds it to d_table with a plain read-modify-write.  Bitwise
+ * reproducible for a given contribution order (torch's embedding_dense_backward is deterministic on the CPU path the
+ * reference oracle runs; the atomic kernel above is the fast default).                                                */
+HM_API int hm_encode_rows(const hm_grid_desc *desc, const float *x, int64_t n, int frac_mode, int32_t *keys_out,
+                          float *weights_out, void *stream);
+HM_API int hm_encode_bwd_table_sorted(const hm_grid_desc *desc, const int32_t *keys_sorted, const int64_t *perm,
+                                      int64_t n_keys, int corners, const float *d_feat, int64_t d_feat_stride,
+                                      const float *weights, float *d_table, void *stream);
+
 /* ---- fused SDF network forward (no grad) ---------------------------------------------------
  * Replaces ImplicitNetwork.forward evaluated under torch.no_grad()
  * (model/implicit_differentiable_renderer.py:89-113 + density_net.py:20-30), i.e. the `sdf`

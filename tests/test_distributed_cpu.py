@@ -41,6 +41,8 @@ def _build():
     inp, gt = bench.synthetic_batch(5, 64, "cpu")
     rs = np.random.RandomState(3)
     inp["object_mask"] = torch.from_numpy(rs.uniform(0, 1, (1, 64)) < 0.8)
+    inp["object_mask"][:, 48:] = False     # the last quarter of the rays has no surface: with 4 ranks, rank 3's shard
+                                           # renders nothing and the rendering network gets no gradient there
     gt["rgb"] = torch.from_numpy(rs.uniform(-1, 1, (1, 64, 3)).astype(np.float32))
     return ref, IDRLoss(eikonal_weight=0.1, mask_weight=100.0, alpha=50.0), inp, gt
 
@@ -72,8 +74,8 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(600)
-def test_two_rank_mean_allreduce_matches_single_process():
-    world = 2
+@pytest.mark.parametrize("world", [2, 4])      # 4: rank 3 holds an empty-surface shard (no rendering-net gradient)
+def test_mean_allreduce_matches_single_process(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -106,10 +108,72 @@ def test_two_rank_mean_allreduce_matches_single_process():
                 continue
             want = (acc[n] / world).numpy()
             np.testing.assert_allclose(g, want, rtol=1e-6, atol=1e-6 * max(np.abs(want).max(), 1e-12), err_msg=n)
-    # both ranks hold identical averaged gradients
-    for n in res[0][1]:
-        if res[0][1][n] is not None:
-            assert np.array_equal(res[0][1][n], res[1][1][n]), n
+    # all ranks hold identical averaged gradients
+    for r in range(1, world):
+        for n in res[0][1]:
+            if res[0][1][n] is not None:
+                assert np.array_equal(res[0][1][n], res[r][1][n]), (r, n)
+    if world == 4:      # the empty shard really was empty: rank 3 alone produced no rendering-network gradient
+        ref3, loss_fn, inp, gt = _build()
+        _shard_grads(ref3, loss_fn, inp, gt, 3, 4)
+        assert all(p.grad is None for n, p in ref3.named_parameters() if n.startswith("rendering_network."))
+
+
+def _sparse_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from hashmodnffbanks_idr_amd import parallel
+    parallel.init_distributed(backend="gloo")
+    rows, F = 5000, 2
+    table = torch.nn.Parameter(torch.zeros(rows, F))
+    other = torch.nn.Parameter(torch.zeros(7, 3))
+    ex = parallel.RowValueExchange(table)
+    red = parallel.GradAllReducer([table, other], big_numel=256, sparse=[ex])
+    red.assume_dense = True
+    out = []
+    for step in range(3):                 # the same exchange object over several steps (static capacity)
+        rs = np.random.RandomState(100 * step + rank)
+        ex.begin_step()
+        dense = torch.zeros(rows, F)
+        if not (rank == world - 1 and step != 1):          # the last rank contributes nothing in steps 0 and 2
+            for _ in range(2):                              # two contributions per step, rows repeat
+                idx = torch.from_numpy(rs.randint(0, rows, 300))
+                val = torch.from_numpy(rs.standard_normal((300, F)).astype(np.float32))
+                ex.add(idx, val)
+                dense.index_add_(0, idx, val)
+        other.grad = torch.full((7, 3), float(rank + step))
+        red()
+        want = dense.clone()
+        dist.all_reduce(want)                               # dense route of the same gradient
+        want /= world
+        out.append((table.grad.clone().numpy(), want.numpy(), other.grad.clone().numpy()))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 4])
+def test_sparse_row_value_exchange_equals_dense_mean(world):
+    """parallel.RowValueExchange: all-gather of (row, value) pairs + local scatter == mean all-reduce of the dense
+    gradient, including a rank with no contribution at all and repeated rows; the dense bucket next to it still works."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sparse_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in range(world):
+        for step, (got, want, other) in enumerate(res[r]):
+            np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6)
+            assert np.count_nonzero(want) > 0
+            np.testing.assert_allclose(other, np.full((7, 3), np.mean([k + step for k in range(world)])), rtol=1e-6)
+            assert np.array_equal(got, res[0][step][0])      # identical on every rank
 
 
 def test_shard_rays_partition():

@@ -45,7 +45,7 @@ def _shard_inputs(bench, rank):
     return inp, gt
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, sparse=False):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port), HM_DIST_BACKEND="gloo")
     from hashmodnffbanks_idr_amd import parallel
@@ -56,7 +56,12 @@ def _worker(rank, world, port, out_dir):
     model, loss_fn, bench = _build()
     inp, gt = _shard_inputs(bench, rank)
     opt = ClipAdam(model.parameters(), lr=LR, max_norm=1.0)
-    stepper = GraphedTrainStep(model, loss_fn, opt, parallel.GradAllReducer(model.parameters()), warmup=2)
+    exchanges = []
+    if sparse:   # table gradients as (point, feature-gradient) pairs instead of the dense all-reduce
+        exchanges = [parallel.PointGradExchange(model.implicit_network.embed_model.embedder_obj),
+                     parallel.PointGradExchange(model.rendering_network.embed_model.embedder_obj)]
+    stepper = GraphedTrainStep(model, loss_fn, opt, parallel.GradAllReducer(model.parameters(), sparse=exchanges),
+                               warmup=2)
     torch.manual_seed(100 + rank)
     rec = {"loss": [], "evals": [], "nonfinite": [], "unfinished": []}
     for _ in range(STEPS):
@@ -106,10 +111,11 @@ def _single_process_reference():
     return rec
 
 
-def test_two_gloo_ranks_follow_the_averaged_gradient_trajectory():
+@pytest.mark.parametrize("sparse", [False, True])
+def test_two_gloo_ranks_follow_the_averaged_gradient_trajectory(sparse):
     import torch.multiprocessing as mp
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(2, _free_port(), d), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, _free_port(), d, sparse), nprocs=2, join=True)
         ranks = [torch.load(os.path.join(d, f"rank{r}.pt"), weights_only=False) for r in range(2)]
     ref = _single_process_reference()
     for r in ranks:

@@ -147,3 +147,27 @@ def test_encode_full_size_properties(cfg):
     lhs = (out[:m, nf:].double() * d_feat.double()).sum().item()
     rhs = (tab.double() * d_table.double()).sum().item()
     assert abs(lhs - rhs) <= 1e-6 * max(1.0, abs(lhs)), (lhs, rhs)
+
+
+@pytest.mark.parametrize("mode", ["reference", "trilinear"])
+def test_deterministic_table_backward(mode):
+    """sort + segmented sum (hm_encode_rows / hm_encode_bwd_table_sorted) == the atomic scatter up to fp32 ordering,
+    and bitwise identical from run to run (many points share rows: coarse levels, duplicated points)."""
+    import params as P
+    from hashmodnffbanks_idr_amd import ops
+    L, T, b, d = P.CONFIGS["C1"]
+    res, rows = P.level_table(L, T, b, d)
+    desc = ops.GridDesc(res, rows, 2)
+    x = torch.from_numpy(P.make_points(5, 20000, -1.0, 1.0)).cuda()
+    x[5000:9000] = x[:4000]
+    g = torch.randn(20000, L * 2, device="cuda")
+    fm = ops.FRAC_MODES[mode]
+    a = ops.encode_bwd_table(desc, x, g, fm)
+    d1 = ops.encode_bwd_table(desc, x, g, fm, deterministic=True)
+    d2 = ops.encode_bwd_table(desc, x, g, fm, deterministic=True)
+    assert torch.equal(d1, d2)
+    scale = a.abs().max().item()
+    assert (a - d1).abs().max().item() <= 2e-5 * scale
+    acc = torch.ones_like(d1)
+    ops.encode_bwd_table(desc, x, g, fm, out=acc, deterministic=True)          # accumulates into the given tensor
+    assert torch.allclose(acc - 1.0, d1, rtol=1e-5, atol=1e-5 * scale)
