@@ -9,21 +9,24 @@
 //     features += out_layer(e),
 // output [u | features / L].  In torch this is ~12 GEMMs of width 56 / 72 plus ~40 elementwise kernels per call.
 //
-// Mapping (gfx950): ONE THREAD PER POINT.  The layers are far too narrow for a matrix tile to pay (56 / 72 columns,
-// a sin or a per-row normalisation after every product), and on gfx950 the fp32 MFMA rate EQUALS the fp32 VALU rate
-// (157 TFLOP/s both), so the exact-fp32 product is written for the VALU with the weights as SCALAR operands: the loop
-// over output features is wave-uniform, each weight row arrives through the scalar cache (s_load_dwordx8/16) and
-// every v_fmac_f32 takes its weight from an SGPR - no LDS operand traffic, no weight registers.  A thread keeps its
-// W activations in registers (static indices); results whose index is the loop counter go through a private LDS
-// column [W][threads] (conflict-free: lane = bank).  k-ordered fma chains, -ffp-contract=off file: the arithmetic is
-// the same dot-product order torch's sgemm uses up to its blocking (parity tolerances in the tests).
+// Mapping (gfx950): EIGHT LANES PER POINT on the VALU.  The layers are far too narrow for a matrix tile to pay
+// (56 / 72 columns, a sin or a per-row normalisation after every product), and on gfx950 the fp32 MFMA rate EQUALS
+// the fp32 VALU rate (157 TFLOP/s both), so the exact-fp32 products run as k-ordered fma chains on the VALU.  Lane s
+// of a point owns rows s, s+8, ... (7 or 9 of them) of every product; its weight rows arrive as 16-byte vector loads
+// from the CU's L1 (the matrices are 12 - 21 KB), the input vector sits replicated in the 8 lanes' registers
+// (static indices), and the outputs are exchanged through a per-point LDS row.  Splitting a point over 8 lanes is
+// what makes the ~50 small calls of a ray search cheap: the first version (one thread per point, weights as scalar
+// operands) had a 120 us serial chain per call however few points it held; here the chain is 8x shorter and a
+// 4096-point round fills every CU.  -ffp-contract=off file: same dot-product order as torch's sgemm up to blocking.
 #include "hm_common.h"
 
 #include <math.h>
 
 namespace {
 
-constexpr int kNT = 128;   // threads (= points) per workgroup: 2 x [72][128] floats of LDS = 73.7 KB -> two per CU
+constexpr int kNT = 256;   // threads per workgroup
+constexpr int kLP = 8;     // lanes per point: each lane owns W/8 of every layer's outputs (W = 56 / 72)
+constexpr int kPP = kNT / kLP;   // points per workgroup (32)
 
 struct NffbArgs {   // by value
     const float *trunk_w[HM_MAX_LEVELS];   // ff_lin0 [W,3], ff_lin1.. [W,W]
@@ -47,17 +50,42 @@ __device__ __forceinline__ void nffb_corner(float x, int32_t res, int bit, uint3
     }
 }
 
-// y[j] = b[j] + sum_k Wm[j][k] * v[k], j = 0..W-1 (wave-uniform loop: weights are scalar operands), written to this
-// thread's LDS column col[j * kNT]
-template <int W, int K>
-__device__ __forceinline__ void matvec_to_lds(const float *__restrict__ Wm, const float *__restrict__ b,
-                                              const float (&v)[K], float *col) {
-    for (int j = 0; j < W; ++j) {
-        const float *row = Wm + j * K;
-        float acc = __fmul_rn(row[0], v[0]);
+// Lane `sub` of a point computes rows sub, sub + 8, ... of y = Wm v + b (k-ordered fma chain per row, the weights
+// read as 16-byte vector loads: the matrices are 12 - 21 KB and stay in the CU's L1) and leaves them in the point's LDS
+// row; the barrier-separated read-back gives every lane of the point the whole vector again.
+// SINE: the Sine activation sin(w0 .) is applied by the lane that owns the row, BEFORE the exchange (applied after the
+// read-back every one of the 8 lanes would evaluate all W sines again).
+template <int W, int K, bool SINE>
+__device__ __forceinline__ void matvec_rows(const float *__restrict__ Wm, const float *__restrict__ b,
+                                            const float (&v)[K], int sub, float *prow, float w0 = 0.0f) {
+    constexpr int R = W / kLP;
 #pragma unroll
-        for (int k = 1; k < K; ++k) acc = __fmaf_rn(row[k], v[k], acc);
-        col[j * kNT] = __fadd_rn(acc, b[j]);
+    for (int r = 0; r < R; ++r) {
+        const int jrow = sub + kLP * r;
+        const float *row = Wm + jrow * K;
+        float acc;
+        if (K % 4 == 0) {
+            const float4 *row4 = reinterpret_cast<const float4 *>(row);
+            float4 w4 = row4[0];
+            acc = __fmul_rn(w4.x, v[0]);
+            acc = __fmaf_rn(w4.y, v[1], acc);
+            acc = __fmaf_rn(w4.z, v[2], acc);
+            acc = __fmaf_rn(w4.w, v[3], acc);
+#pragma unroll
+            for (int k4 = 1; k4 < K / 4; ++k4) {
+                w4 = row4[k4];
+                acc = __fmaf_rn(w4.x, v[4 * k4], acc);
+                acc = __fmaf_rn(w4.y, v[4 * k4 + 1], acc);
+                acc = __fmaf_rn(w4.z, v[4 * k4 + 2], acc);
+                acc = __fmaf_rn(w4.w, v[4 * k4 + 3], acc);
+            }
+        } else {
+            acc = __fmul_rn(row[0], v[0]);
+#pragma unroll
+            for (int k = 1; k < K; ++k) acc = __fmaf_rn(row[k], v[k], acc);
+        }
+        const float y = __fadd_rn(acc, b[jrow]);
+        prow[jrow] = SINE ? sinf(__fmul_rn(y, w0)) : y;
     }
 }
 
@@ -67,15 +95,18 @@ __global__ __launch_bounds__(kNT) void nffb_fwd_kernel(HmLevels lv, NffbArgs a, 
                                                        const float *__restrict__ Bf, float *__restrict__ out,
                                                        int64_t out_stride, const int32_t *__restrict__ n_dev) {
     constexpr int W = 8 + 8 * LV;
+    constexpr int R = W / kLP;
     constexpr int NG = 4 * (LV - 2);   // grid values that are ever consumed: chunks 0 .. LV-3
-    extern __shared__ __align__(16) float nffb_lds[];
-    float *T = nffb_lds;               // [W][kNT] dynamic-index results of the current product
-    float *FE = nffb_lds + W * kNT;    // [W][kNT] feature accumulator
+    constexpr int WP = W + 4;          // padded LDS row (keeps 16-byte alignment, staggers the banks of the 32 rows)
+    __shared__ __align__(16) float T[kPP * WP];    // per point: the vector being exchanged between its 8 lanes
+    __shared__ float G[kPP * NG];                  // per point: the consumed part of the grid row
     if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));
     const int tid = threadIdx.x;
-    float *tcol = T + tid, *fcol = FE + tid;
-    for (int64_t base = (int64_t)blockIdx.x * kNT; base < n; base += (int64_t)gridDim.x * kNT) {
-        const int64_t i = base + tid;
+    const int pt = tid / kLP, sub = tid % kLP;
+    float *prow = T + pt * WP;
+    float *grow = G + pt * NG;
+    for (int64_t base = (int64_t)blockIdx.x * kPP; base < n; base += (int64_t)gridDim.x * kPP) {
+        const int64_t i = base + pt;
         const bool live = i < n;
         const float p0 = live ? x[i * 3] : 0.0f, p1 = live ? x[i * 3 + 1] : 0.0f, p2 = live ? x[i * 3 + 2] : 0.0f;
         // trunk input and grid input (nffb3d.py:131-132)
@@ -83,23 +114,22 @@ __global__ __launch_bounds__(kNT) void nffb_fwd_kernel(HmLevels lv, NffbArgs a, 
         const float two_b = __fmul_rn(2.0f, a.bound);
         const float u0 = __fdiv_rn(__fadd_rn(p0, a.bound), two_b), u1 = __fdiv_rn(__fadd_rn(p1, a.bound), two_b),
                     u2 = __fdiv_rn(__fadd_rn(p2, a.bound), two_b);
-        // ---- grid row without its 3 pass-through columns: [sin(L) | cos(L) | level features], first NG values ----
-        float g[NG];
+        __syncthreads();   // the previous tile has left T / G
+        // ---- grid row without its 3 pass-through columns: [sin(L) | cos(L) | level features]; the 8 lanes of a
+        //      point share the 2L sin/cos channels and the (<= L-4) consumed levels ------------------------------
         {
             const float two_pi = 6.283185307179586f;
             const float s0 = __fmul_rn(two_pi, u0), s1 = __fmul_rn(two_pi, u1), s2 = __fmul_rn(two_pi, u2);
-#pragma unroll
-            for (int c = 0; c < LV; ++c) {
+            for (int c = sub; c < LV; c += kLP) {
                 float ang = __fmul_rn(s0, Bf[c]);
                 ang = __fmaf_rn(s1, Bf[LV + c], ang);
                 ang = __fmaf_rn(s2, Bf[2 * LV + c], ang);
                 float sn, cs;
                 sincosf(ang, &sn, &cs);
-                if (c < NG) g[c] = sn;
-                if (LV + c < NG) g[LV + c] = cs;
+                if (c < NG) grow[c] = sn;
+                if (LV + c < NG) grow[LV + c] = cs;
             }
-#pragma unroll
-            for (int l = 0; l < LV; ++l) {
+            for (int l = sub; l < LV; l += kLP) {
                 if (2 * LV + 2 * l >= NG) continue;      // levels beyond L-5 never reach the output
                 float acc0 = 0.0f, acc1 = 0.0f;
                 const float2 *tl = reinterpret_cast<const float2 *>(table) + lv.row_off[l];
@@ -117,60 +147,55 @@ __global__ __launch_bounds__(kNT) void nffb_fwd_kernel(HmLevels lv, NffbArgs a, 
                         acc1 = __fadd_rn(acc1, __fmul_rn(r.y, w));
                     }
                 }
-                g[2 * LV + 2 * l] = acc0;
-                if (2 * LV + 2 * l + 1 < NG) g[2 * LV + 2 * l + 1] = acc1;
+                grow[2 * LV + 2 * l] = acc0;
+                if (2 * LV + 2 * l + 1 < NG) grow[2 * LV + 2 * l + 1] = acc1;
             }
         }
         // ---- trunk layer 0: 3 -> W, sin(w0 .) ------------------------------------------------------------------
         float xv[W];
-        matvec_to_lds<W, 3>(a.trunk_w[0], a.trunk_b[0], xn, tcol);
+        float feat[R];     // this lane's rows of the feature accumulator
 #pragma unroll
-        for (int k = 0; k < W; ++k) {
-            xv[k] = sinf(__fmul_rn(tcol[k * kNT], a.w0));
-            fcol[k * kNT] = 0.0f;
-        }
+        for (int r = 0; r < R; ++r) feat[r] = 0.0f;
+        matvec_rows<W, 3, true>(a.trunk_w[0], a.trunk_b[0], xn, sub, prow, a.w0);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < W; ++k) xv[k] = prow[k];
         // ---- layers 1 .. LV-2 --------------------------------------------------------------------------------------
 #pragma unroll 1
         for (int layer = 1; layer < LV - 1; ++layer) {
-            matvec_to_lds<W, W>(a.trunk_w[layer], a.trunk_b[layer], xv, tcol);
+            __syncthreads();
+            matvec_rows<W, W, true>(a.trunk_w[layer], a.trunk_b[layer], xv, sub, prow, a.w0);
+            __syncthreads();
 #pragma unroll
-            for (int k = 0; k < W; ++k) xv[k] = sinf(__fmul_rn(tcol[k * kNT], a.w0));
-            // positional encoding of chunk layer-1: [c, c, sin(c f0), cos(c f0), sin(c f1), ...], f_m = 2^m
-            float e[W];
-            {
-                float c4[4];
+            for (int k = 0; k < W; ++k) xv[k] = prow[k];
+            // positional encoding of chunk layer-1: [c, c, sin(c f0), cos(c f0), sin(c f1), ...], f_m = 2^m;
+            // lane `sub` computes entries sub, sub + 8, ...: entry k >= 8 is sin (k % 8 < 4) or cos of c[k % 4] * 2^((k-8)/8)
+            __syncthreads();
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {   // g[] is register-resident: select with a static unrolled scan
-                    float v = 0.0f;
-#pragma unroll
-                    for (int m = 0; m < NG; ++m) v = (m == 4 * (layer - 1) + r) ? g[m] : v;
-                    c4[r] = v;
+            for (int r = 0; r < R; ++r) {
+                const int k = sub + kLP * r;
+                const float c = grow[4 * (layer - 1) + (k & 3)];
+                float v = c;
+                if (k >= 8) {
+                    const float arg = __fmul_rn(c, (float)(1 << ((k - 8) >> 3)));
+                    v = (k & 4) ? cosf(arg) : sinf(arg);
                 }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    e[r] = c4[r];
-                    e[4 + r] = c4[r];
-                }
-#pragma unroll
-                for (int m = 0; m < LV; ++m) {
-                    const float f = (float)(1 << m);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float sn, cs;
-                        sincosf(__fmul_rn(c4[r], f), &sn, &cs);
-                        e[8 + 8 * m + r] = sn;
-                        e[8 + 8 * m + 4 + r] = cs;
-                    }
-                }
+                prow[k] = v;
             }
+            __syncthreads();
+            float e[W];
+#pragma unroll
+            for (int k = 0; k < W; ++k) e[k] = prow[k];
             if (STYLE) {
                 // StyleAttention: linear_transform(e) * softmax over a size-1 dim (== 1), then the per-row
                 // InstanceNorm over the W features (biased variance), styleMod.py:30-43
-                matvec_to_lds<W, W>(a.style_w, a.style_b, e, tcol);
+                __syncthreads();
+                matvec_rows<W, W, false>(a.style_w, a.style_b, e, sub, prow);
+                __syncthreads();
                 float mean = 0.0f;
 #pragma unroll
                 for (int k = 0; k < W; ++k) {
-                    e[k] = tcol[k * kNT];
+                    e[k] = prow[k];
                     mean += e[k];
                 }
                 mean = mean / (float)W;
@@ -187,15 +212,17 @@ __global__ __launch_bounds__(kNT) void nffb_fwd_kernel(HmLevels lv, NffbArgs a, 
             }
 #pragma unroll
             for (int k = 0; k < W; ++k) e[k] = __fadd_rn(e[k], xv[k]);
-            matvec_to_lds<W, W>(a.out_w, a.out_b, e, tcol);
+            __syncthreads();
+            matvec_rows<W, W, false>(a.out_w, a.out_b, e, sub, prow);
+            // (each lane reads back only the rows it wrote: no barrier needed)
 #pragma unroll
-            for (int k = 0; k < W; ++k) fcol[k * kNT] = __fadd_rn(fcol[k * kNT], tcol[k * kNT]);
+            for (int r = 0; r < R; ++r) feat[r] = __fadd_rn(feat[r], prow[sub + kLP * r]);
         }
         if (live) {
             float *o = out + i * out_stride;
-            o[0] = u0; o[1] = u1; o[2] = u2;
+            if (sub < 3) o[sub] = sub == 0 ? u0 : (sub == 1 ? u1 : u2);
 #pragma unroll
-            for (int k = 0; k < W; ++k) o[3 + k] = __fdiv_rn(fcol[k * kNT], (float)LV);
+            for (int r = 0; r < R; ++r) o[3 + sub + kLP * r] = __fdiv_rn(feat[r], (float)LV);
         }
     }
 }
@@ -205,15 +232,7 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 template <int FRAC, int LV, bool STYLE>
 int launch_nffb1(unsigned grid, hipStream_t st, const HmLevels &lv, const NffbArgs &a, const float *x, int64_t n,
                  const float *table, const float *Bf, float *out, int64_t out_stride, const int32_t *n_dev) {
-    const size_t lds = sizeof(float) * 2 * (8 + 8 * LV) * kNT;
-    static thread_local bool attr_done = false;   // (one flag per template instance)
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(nffb_fwd_kernel<FRAC, LV, STYLE>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        if (e != hipSuccess) return hm_fail(HM_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
-        attr_done = true;
-    }
-    hipLaunchKernelGGL((nffb_fwd_kernel<FRAC, LV, STYLE>), dim3(grid), dim3(kNT), lds, st, lv, a, x, n, table, Bf, out,
+    hipLaunchKernelGGL((nffb_fwd_kernel<FRAC, LV, STYLE>), dim3(grid), dim3(kNT), 0, st, lv, a, x, n, table, Bf, out,
                        out_stride, n_dev);
     return HM_OK;
 }
@@ -254,8 +273,8 @@ int hm_nffb_fwd(const hm_grid_desc *desc, const hm_nffb_desc *nf, const float *x
     HM_CHECK_ARG((nf->style_w == nullptr) == (nf->style_b == nullptr), "hm_nffb_fwd: style weight / bias must come together");
     a.bound = nf->bound; a.w0 = nf->w0; a.style_eps = nf->style_eps;
     const bool style = nf->style_w != nullptr;
-    const int64_t blocks = (n + kNT - 1) / kNT;
-    const unsigned grid = (unsigned)(blocks < 2048 ? blocks : 2048);
+    const int64_t blocks = (n + kPP - 1) / kPP;
+    const unsigned grid = (unsigned)(blocks < 4096 ? blocks : 4096);
     hipStream_t st = as_stream(stream);
     int rc;
 #define HM_NFFB(FR)                                                                                                    \
