@@ -487,7 +487,7 @@ def main():
         model = _build(cfg, device, lr)
         model.implicit_network.bf16_coarse_search = use_bf16
         reducer = None
-        if world > 1:
+        if world > 1 or os.environ.get("HM_DIST_FORCE") == "1":   # (HM_DIST_FORCE: single-rank RCCL rehearsal)
             # hash-table gradients travel as (point, feature-gradient) pairs (parallel.PointGradExchange, ~0.7 MB per
             # rank instead of 40 / 224 MB dense) in the static graph step; HM_DP_SPARSE=0 or --no-graph: dense all-reduce
             exchanges = []

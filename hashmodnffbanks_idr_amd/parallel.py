@@ -31,13 +31,17 @@ def init_distributed(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # HM_DIST_FORCE=1: create the process group for a single rank too (rehearses the RCCL code path on one GPU)
+    if (world > 1 or os.environ.get("HM_DIST_FORCE") == "1") and not dist.is_initialized():
         if backend is None:
             # "nccl" IS RCCL on ROCm.  HM_DIST_BACKEND=gloo lets the N>1 path be rehearsed with several
             # ranks on ONE GPU (RCCL refuses two ranks per device).
             backend = os.environ.get("HM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
 
@@ -78,8 +82,8 @@ class _SparseExchange:
         dev = self.param.device
         if self.payload is None or self.cursor + n > self.payload.shape[0]:
             if self._gathered is not None:
-                raise RuntimeError("sparse gradient exchange: more contributions than the fixed capacity "
-                                   "(the step is not static)")
+                raise RuntimeError("sparse gradient exchange: more contributions than the capacity fixed by the first "
+                                   "exchange (the step is not static)")
             new = torch.zeros((max(2 * (self.cursor + n), 1024), self.width), dtype=torch.float32, device=dev)
             if self.payload is not None and self.cursor:
                 new[:self.cursor].copy_(self.payload[:self.cursor])
@@ -89,20 +93,26 @@ class _SparseExchange:
         return view
 
     def exchange(self, world):
-        if self.payload is None:
-            self.payload = torch.zeros((1024, self.width), dtype=torch.float32, device=self.param.device)
-        if self.cursor < self.payload.shape[0]:
+        dev = self.param.device
+        if self._gathered is None:
+            # first exchange: the ranks agree on ONE capacity = the largest row count of this step (static steps repeat
+            # it exactly; a rank with fewer rows pads with zero rows, which add nothing).  No slack is kept: padding
+            # rows all land on one table row per level and would serialise the deterministic scatter's run sum.
+            need = torch.tensor([max(self.cursor, 1)], device=dev, dtype=torch.int64)
+            dist.all_reduce(need, op=dist.ReduceOp.MAX)
+            cap = int(need)
+            fixed = torch.zeros((cap, self.width), dtype=torch.float32, device=dev)
+            if self.payload is not None and self.cursor:
+                fixed[:self.cursor].copy_(self.payload[:self.cursor])
+            self.payload = fixed
+            self._gathered = torch.empty((world * cap, self.width), dtype=torch.float32, device=dev)
+        elif self.cursor < self.payload.shape[0]:
             self.payload[self.cursor:].zero_()          # stale rows of an earlier, larger step must add nothing
         cap = self.payload.shape[0]
-        if self._gathered is None or self._gathered.shape[0] != world * cap:
-            caps = torch.tensor([cap], device=self.param.device, dtype=torch.int64)
-            lo, hi = caps.clone(), caps.clone()
-            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-            if int(lo) != int(hi):
-                raise RuntimeError("sparse gradient exchange: ranks disagree on the payload capacity")
-            self._gathered = torch.empty((world * cap, self.width), dtype=torch.float32, device=self.param.device)
-        dist.all_gather(list(self._gathered.split(cap, 0)), self.payload)
+        if dist.get_backend() == "nccl":      # RCCL: one all-gather straight into the flat buffer
+            dist.all_gather_into_tensor(self._gathered, self.payload)
+        else:
+            dist.all_gather(list(self._gathered.split(cap, 0)), self.payload)
         if self.dense is None or self.dense.shape != self.param.shape or self.dense.device != self.param.device:
             self.dense = torch.zeros_like(self.param)
         else:
@@ -177,7 +187,7 @@ class GradAllReducer:
         self._views = None
 
     def __call__(self):
-        if not dist.is_initialized() or dist.get_world_size() == 1:
+        if not dist.is_initialized() or (dist.get_world_size() == 1 and os.environ.get("HM_DIST_FORCE") != "1"):
             return
         world = dist.get_world_size()
         dev = self.params[0].device
