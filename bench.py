@@ -170,7 +170,7 @@ def gather_roofline(emb, log2_n=22, iters=10, warmup=3):
                     "algorithmic bytes"}
 
 
-def gather_bwd_roofline(emb, log2_n=22, iters=10, warmup=3):
+def gather_bwd_roofline(emb, log2_n=22, iters=10, warmup=3, frac_mode=0):
     """Table-gradient scatter (hm_encode_bwd_table): 12 + L*F*4 + L*8*F*4*2 algorithmic bytes/point
     (the RMW of all 8 corner rows is counted although zero-weight corners are skipped)."""
     from hashmodnffbanks_idr_amd import ops
@@ -182,21 +182,27 @@ def gather_bwd_roofline(emb, log2_n=22, iters=10, warmup=3):
     d_feat = torch.randn((n, L * F), device=dev)
     d_table = torch.zeros_like(emb.table)
     for _ in range(warmup):
-        ops.encode_bwd_table(emb.desc, x, d_feat, 0, out=d_table)
+        ops.encode_bwd_table(emb.desc, x, d_feat, frac_mode, out=d_table)
     torch.cuda.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
     for s, e in evs:
         s.record()
-        ops.encode_bwd_table(emb.desc, x, d_feat, 0, out=d_table)
+        ops.encode_bwd_table(emb.desc, x, d_feat, frac_mode, out=d_table)
         e.record()
     torch.cuda.synchronize()
     ms = np.asarray([s.elapsed_time(e) for s, e in evs])
     bpp = 12 + L * F * 4 + L * 8 * F * 4 * 2
     avg_ms = float(ms.mean())
     achieved = n * bpp / (avg_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "encode_bwd_table_kernel",
-            "units_per_launch": n, "bytes_per_unit": bpp, "avg_launch_ms": round(avg_ms, 4)}
+    rec = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+           "kernel": "encode_bwd_table_zorder_kernel (+ 3 bucketing passes + the z-order pack pass, inside the timed launch)",
+           "units_per_launch": n, "bytes_per_unit": bpp, "avg_launch_ms": round(avg_ms, 4),
+           "frac_mode": "trilinear (all 8 corners carry weight)" if frac_mode else
+                        "reference (only corner 0 carries weight: 1/8 of the read-modify-writes the byte count assumes)"}
+    if frac_mode == 0:
+        rec["all_corners"] = gather_bwd_roofline(emb, log2_n, max(2, iters // 2), 1, frac_mode=1)
+    return rec
 
 
 def mlp_roofline(net, log2_n=18, iters=5, warmup=2):

@@ -31,6 +31,8 @@ SIGNATURES = {
     "hm_encode_workspace_bytes": (_i64, [_p, _i64]),
     "hm_encode_fwd_ws": (_int, [_p, _p, _i64, _p, _p, _p, _i64, _int, _p, _i64, _p]),
     "hm_encode_bwd_table": (_int, [_p, _p, _i64, _p, _i64, _p, _int, _p]),
+    "hm_encode_bwd_workspace_bytes": (_i64, [_p, _i64]),
+    "hm_encode_bwd_table_ws": (_int, [_p, _p, _i64, _p, _i64, _p, _int, _p, _i64, _p]),
     "hm_encode_rows": (_int, [_p, _p, _i64, _int, _p, _p, _p]),
     "hm_encode_bwd_table_sorted": (_int, [_p, _p, _p, _i64, _int, _p, _i64, _p, _p, _p]),
     "hm_sdf_fwd": (_int, [_p, _p, _p, _i64, _p, _p, _p, _i64, _int, _int, _int, _p, _int, _p]),

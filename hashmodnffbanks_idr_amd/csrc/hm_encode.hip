@@ -330,7 +330,9 @@ __global__ __launch_bounds__(1024) void zsort_hist_kernel(const float *__restric
         if (h[i]) atomicAdd(&hist[i], h[i]);
 }
 
-__global__ __launch_bounds__(kSlabs) void zsort_scan_kernel(uint32_t *hist /* in: counts, out: start offsets */) {
+// hist[0..kSlabs): counts -> start offsets (the scatter pass turns them into end offsets);
+// hist[kSlabs..2 kSlabs): a copy of the start offsets that survives the scatter
+__global__ __launch_bounds__(kSlabs) void zsort_scan_kernel(uint32_t *hist) {
     __shared__ uint32_t s[kSlabs];
     const int t = threadIdx.x;
     s[t] = hist[t];
@@ -341,7 +343,9 @@ __global__ __launch_bounds__(kSlabs) void zsort_scan_kernel(uint32_t *hist /* in
         s[t] += v;
         __syncthreads();
     }
-    hist[t] = s[t] - hist[t];   // exclusive
+    const uint32_t start = s[t] - hist[t];   // exclusive
+    hist[t] = start;
+    hist[kSlabs + t] = start;
 }
 
 __global__ __launch_bounds__(1024) void zsort_scatter_kernel(const float *__restrict__ x, int64_t n, uint32_t *cursor,
@@ -569,6 +573,114 @@ __global__ __launch_bounds__(kThreads) void encode_bwd_table_kernel(HmLevels lv,
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// z-ordered table gradient for big launches (F = 2).  Scattering one 4-byte atomic per lane into 64 different rows
+// runs at a sixteenth of the atomic rate (the guide's 0.08 TB/s case): the atomic kernel above needs 8.2 ms for 2^22
+// points.  With the points bucketed into z-slabs (same three passes as the forward) every (slab, level) pair touches
+// only a handful of 2^11-row blocks of its level's table (the z-plane windows, see encode_fwd_f2_zorder_kernel), so
+// one workgroup per pair accumulates its contributions in LDS copies of those blocks (ds_add_f32) and then adds each
+// block to the table with DENSE, fully coalesced float atomics - 256 contiguous bytes per wave instruction, the shape
+// that runs at the full 1.3 TB/s.  A pre-pass lays x and d_feat out in z order, level-major, so that the per-level
+// passes read contiguous 8-byte values instead of re-gathering 128-byte rows 16 times.  Contributions that do not find
+// a free LDS block (more than kBwdSlots distinct blocks in one pair: never seen in [-1,1]^3) go straight to the table.
+constexpr int kBwdSlots = 8;            // LDS blocks per workgroup: 8 x 2048 rows x 2 floats = 128 KB
+constexpr int kBwdBlockRows = 2048;
+constexpr int kBwdThreads = 512;
+
+__global__ __launch_bounds__(256) void zsort_pack_kernel(const float *__restrict__ x, const float *__restrict__ d_feat,
+                                                         int64_t d_feat_stride, const uint32_t *__restrict__ order,
+                                                         int64_t n, int LF, float *__restrict__ xs,
+                                                         float *__restrict__ dfs /* [LF/2][n][2] */) {
+    __shared__ float tile[64 * 33];      // 64 points x up to 32 floats (+1 pad)
+    const int64_t k0 = (int64_t)blockIdx.x * 64;
+    const int tid = threadIdx.x;
+    for (int c0 = 0; c0 < LF; c0 += 32) {
+        const int cw = min(32, LF - c0);
+        __syncthreads();
+        for (int i = tid; i < 64 * cw; i += 256) {      // coalesced along a point's row
+            const int p = i / cw, c = i - p * cw;
+            const int64_t k = k0 + p;
+            tile[p * 33 + c] = k < n ? d_feat[(int64_t)order[k] * d_feat_stride + c0 + c] : 0.0f;
+        }
+        __syncthreads();
+        for (int i = tid; i < 64 * cw; i += 256) {      // coalesced along the points of one level
+            const int pr = i / 128, r = i - pr * 128;   // level pair index within the chunk, (point, f)
+            const int p = r >> 1, f = r & 1;
+            const int64_t k = k0 + p;
+            if (2 * pr + f < cw && k < n) dfs[((int64_t)(c0 / 2 + pr) * n + k) * 2 + f] = tile[p * 33 + 2 * pr + f];
+        }
+    }
+    for (int i = tid; i < 64 * 3; i += 256) {
+        const int p = i / 3, c = i - p * 3;
+        const int64_t k = k0 + p;
+        if (k < n) xs[k * 3 + c] = x[(int64_t)order[k] * 3 + c];
+    }
+}
+
+template <int FRAC>
+__global__ __launch_bounds__(kBwdThreads) void encode_bwd_table_zorder_kernel(HmLevels lv,
+                                                                             const float *__restrict__ xs,
+                                                                             const float2 *__restrict__ dfs, int64_t n,
+                                                                             const uint32_t *__restrict__ slab_start,
+                                                                             float *__restrict__ d_table) {
+    extern __shared__ __align__(16) float smem[];
+    float *acc = smem;                                                  // [kBwdSlots][kBwdBlockRows][2]
+    uint32_t *keys = reinterpret_cast<uint32_t *>(smem + kBwdSlots * kBwdBlockRows * 2);   // [kBwdSlots]
+    const int slab = blockIdx.x, l = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int64_t beg = slab_start[slab], end = slab + 1 < kSlabs ? (int64_t)slab_start[slab + 1] : n;
+    if (beg >= end) return;
+    for (int i = tid; i < kBwdSlots * kBwdBlockRows * 2; i += kBwdThreads) acc[i] = 0.0f;
+    if (tid < kBwdSlots) keys[tid] = 0xffffffffu;
+    __syncthreads();
+    const int32_t res = lv.res[l];
+    const uint32_t rows = lv.rows[l], magic = lv.magic[l];
+    const float2 *g = dfs + (int64_t)l * n;
+    float *tl = d_table + (size_t)lv.row_off[l] * 2;
+    constexpr int C = FRAC == HM_FRAC_REFERENCE ? 1 : 8;
+    for (int64_t k = beg + tid; k < end; k += kBwdThreads) {
+        const float x0 = xs[k * 3], x1 = xs[k * 3 + 1], x2 = xs[k * 3 + 2];
+        const float2 gv = g[k];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            uint32_t ux, uy, uz;
+            float wx, wy, wz;
+            voxel_and_weight<FRAC>(x0, res, c & 1, ux, wx);
+            voxel_and_weight<FRAC>(x1, res, (c >> 1) & 1, uy, wy);
+            voxel_and_weight<FRAC>(x2, res, (c >> 2) & 1, uz, wz);
+            const float w = __fmul_rn(__fmul_rn(wx, wy), wz);
+            if (w == 0.0f) continue;
+            const uint32_t id = hm_mod_rows(hm_hash3(ux, uy, uz), rows, magic);
+            const uint32_t blk = id / kBwdBlockRows, off = id % kBwdBlockRows;
+            int slot = -1;
+            for (int s = 0; s < kBwdSlots; ++s) {
+                uint32_t cur = keys[s];
+                if (cur == 0xffffffffu) cur = atomicCAS(&keys[s], 0xffffffffu, blk);
+                if (cur == blk || cur == 0xffffffffu) { slot = s; break; }
+            }
+            const float v0 = __fmul_rn(w, gv.x), v1 = __fmul_rn(w, gv.y);
+            if (slot >= 0) {
+                atomicAdd(&acc[(slot * kBwdBlockRows + off) * 2], v0);
+                atomicAdd(&acc[(slot * kBwdBlockRows + off) * 2 + 1], v1);
+            } else {
+                atomicAdd(tl + (size_t)id * 2, v0);
+                atomicAdd(tl + (size_t)id * 2 + 1, v1);
+            }
+        }
+    }
+    __syncthreads();
+    for (int s = 0; s < kBwdSlots; ++s) {
+        const uint32_t blk = keys[s];
+        if (blk == 0xffffffffu) break;
+        const uint32_t row0 = blk * kBwdBlockRows;
+        const uint32_t nrow = min((uint32_t)kBwdBlockRows, rows - row0);
+        for (uint32_t i = tid; i < nrow * 2; i += kBwdThreads) {      // dense, coalesced atomics
+            const float v = acc[s * kBwdBlockRows * 2 + i];
+            if (v != 0.0f) atomicAdd(tl + (size_t)row0 * 2 + i, v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Deterministic table gradient (no atomics): contributions are keyed by their destination row, sorted by the caller
 // (any stable sort; torch.sort in ops.encode_bwd_table), and every run of equal keys is summed by ONE thread in
 // sorted order and added to the table with a plain read-modify-write (each row has exactly one owner).  Bitwise
@@ -646,6 +758,60 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 }  // namespace
 
 extern "C" {
+
+int64_t hm_encode_bwd_workspace_bytes(const hm_grid_desc *desc, int64_t n) {
+    if (!desc || n < 0) return hm_fail(HM_ERR_INVALID, "hm_encode_bwd_workspace_bytes: bad argument");
+    // [slab counters 2*kSlabs u32 | order n u32 | xs 3n f32 | dfs L*F*n f32], each part 256-byte aligned
+    auto up = [](int64_t b) { return (b + 255) / 256 * 256; };
+    return up(4 * 2 * kSlabs) + up(4 * n) + up(12 * n) + up(4 * n * desc->lv.L * desc->lv.F);
+}
+
+int hm_encode_bwd_table_ws(const hm_grid_desc *desc, const float *x, int64_t n, const float *d_feat,
+                           int64_t d_feat_stride, float *d_table, int frac_mode, void *workspace,
+                           int64_t workspace_bytes, void *stream) {
+    HM_CHECK_ARG(desc != nullptr, "hm_encode_bwd_table_ws: desc is NULL");
+    const HmLevels &lv = desc->lv;
+    const bool table_big = desc->total_rows * (uint64_t)lv.F * 4u > (8u << 20);
+    if (!workspace || lv.F != 2 || n < (int64_t)131072 || n >= ((int64_t)1 << 31) || !table_big ||
+        workspace_bytes < hm_encode_bwd_workspace_bytes(desc, n))
+        return hm_encode_bwd_table(desc, x, n, d_feat, d_feat_stride, d_table, frac_mode, stream);
+    HM_CHECK_ARG(frac_mode == HM_FRAC_REFERENCE || frac_mode == HM_FRAC_TRILINEAR, "hm_encode_bwd_table_ws: bad frac_mode");
+    HM_CHECK_ARG(d_feat_stride >= lv.L * lv.F, "hm_encode_bwd_table_ws: d_feat_stride < L*F");
+    HM_CHECK_ARG(x && d_feat && d_table, "hm_encode_bwd_table_ws: NULL pointer");
+    hipStream_t st = as_stream(stream);
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    char *wsb = static_cast<char *>(workspace);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(wsb);
+    uint32_t *order = reinterpret_cast<uint32_t *>(wsb + up(4 * 2 * kSlabs));
+    float *xs = reinterpret_cast<float *>(wsb + up(4 * 2 * kSlabs) + up(4 * (size_t)n));
+    float *dfs = reinterpret_cast<float *>(wsb + up(4 * 2 * kSlabs) + up(4 * (size_t)n) + up(12 * (size_t)n));
+    hm_zero_u32_async(hist, kSlabs, st);
+    const unsigned g_sort = (unsigned)((n + kSortChunk - 1) / kSortChunk);
+    hipLaunchKernelGGL(zsort_hist_kernel, dim3(g_sort), dim3(1024), 0, st, x, n, hist);
+    hipLaunchKernelGGL(zsort_scan_kernel, dim3(1), dim3(kSlabs), 0, st, hist);
+    hipLaunchKernelGGL(zsort_scatter_kernel, dim3(g_sort), dim3(1024), 0, st, x, n, hist, order);
+    hipLaunchKernelGGL(zsort_pack_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, x, d_feat, d_feat_stride,
+                       order, n, lv.L * lv.F, xs, dfs);
+    static thread_local bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_bwd_table_zorder_kernel<HM_FRAC_REFERENCE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_bwd_table_zorder_kernel<HM_FRAC_TRILINEAR>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return hm_fail(HM_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+        attr_done = true;
+    }
+    const size_t lds = sizeof(float) * kBwdSlots * kBwdBlockRows * 2 + sizeof(uint32_t) * kBwdSlots;
+    if (frac_mode == HM_FRAC_REFERENCE)
+        hipLaunchKernelGGL(encode_bwd_table_zorder_kernel<HM_FRAC_REFERENCE>, dim3(kSlabs, lv.L), dim3(kBwdThreads), lds, st,
+                           lv, xs, reinterpret_cast<const float2 *>(dfs), n, hist + kSlabs, d_table);
+    else
+        hipLaunchKernelGGL(encode_bwd_table_zorder_kernel<HM_FRAC_TRILINEAR>, dim3(kSlabs, lv.L), dim3(kBwdThreads), lds, st,
+                           lv, xs, reinterpret_cast<const float2 *>(dfs), n, hist + kSlabs, d_table);
+    HM_CHECK_LAUNCH("hm_encode_bwd_table_ws");
+    return HM_OK;
+}
 
 int hm_encode_rows(const hm_grid_desc *desc, const float *x, int64_t n, int frac_mode, int32_t *keys_out,
                    float *weights_out, void *stream) {

@@ -77,6 +77,7 @@ def corner_ids(desc, level, x):
     return xi, ids.long() & 0xFFFFFFFF
 
 
+_ENC_BWD_WS = {}   # device -> scratch of the z-ordered table backward
 _ENC_WS = {}   # device -> scratch of the z-ordered encode (grown on demand, reused by every launch on that stream)
 
 
@@ -122,6 +123,14 @@ def encode_bwd_table(desc, x, d_feat, frac_mode=0, out=None, deterministic=False
         skeys, perm = torch.sort(keys, stable=True)
         check(lib().hm_encode_bwd_table_sorted(desc.handle, dptr(skeys), dptr(perm), keys.numel(), corners, dptr(d_feat),
                                                d_feat.stride(0), dptr(wts), dptr(out), stream_ptr(x)))
+        return out
+    if n >= 131072 and desc.F == 2:     # big launches: z-ordered, LDS-privatised scatter (needs scratch)
+        need = check(lib().hm_encode_bwd_workspace_bytes(desc.handle, n))
+        ws = _ENC_BWD_WS.get(x.device)
+        if ws is None or ws.numel() < need:
+            ws = _ENC_BWD_WS[x.device] = torch.empty(need, dtype=torch.uint8, device=x.device)
+        check(lib().hm_encode_bwd_table_ws(desc.handle, dptr(x), n, dptr(d_feat), d_feat.stride(0), dptr(out),
+                                           int(frac_mode), dptr(ws), ws.numel(), stream_ptr(x)))
         return out
     check(lib().hm_encode_bwd_table(desc.handle, dptr(x), n, dptr(d_feat), d_feat.stride(0), dptr(out),
                                     int(frac_mode), stream_ptr(x)))

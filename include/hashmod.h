@@ -107,6 +107,15 @@ HM_API int hm_encode_fwd_ws(const hm_grid_desc *desc, const float *x, int64_t n,
 HM_API int hm_encode_bwd_table(const hm_grid_desc *desc, const float *x, int64_t n, const float *d_feat,
                         int64_t d_feat_stride, float *d_table, int frac_mode, void *stream);
 
+/* Same gradient with a caller-owned scratch buffer of hm_encode_bwd_workspace_bytes(desc, n) bytes.  Big launches
+ * (F = 2, n >= 131072, tables > 8 MiB) bucket the points by z, lay x / d_feat out in that order and let one workgroup
+ * per (z-slab, level) accumulate its contributions in LDS copies of the few 2^11-row blocks it touches before adding
+ * them to d_table with dense, coalesced atomics; otherwise identical to hm_encode_bwd_table.                     */
+HM_API int64_t hm_encode_bwd_workspace_bytes(const hm_grid_desc *desc, int64_t n);
+HM_API int hm_encode_bwd_table_ws(const hm_grid_desc *desc, const float *x, int64_t n, const float *d_feat,
+                                  int64_t d_feat_stride, float *d_table, int frac_mode, void *workspace,
+                                  int64_t workspace_bytes, void *stream);
+
 /* Deterministic form of the same gradient (no atomics).  hm_encode_rows lists, for every (point, level[, corner]),
  * the destination row in the fused table (keys_out [n*L*C] int32, C = 1 in reference frac mode - only corner 0 carries
  * weight - and 8 in trilinear mode, where weights_out [n*L*C] receives the interpolation weights).  The caller sorts

@@ -386,6 +386,91 @@ def gen_idr_step_C2():
     gen_idr_step("C2", 2048, 52, 1, bias=1.0)
 
 
+def gen_idr_step_C4():
+    """BASELINE configs[3] per-GPU shape: T = 2^22 (223.5 MiB of tables), 2048 rays, one iteration."""
+    gen_idr_step("C4", 2048, 53, 1, bias=1.0)
+
+
+NFFB_STEP = {"C3": ("FFB", 4096, 54), "C5": ("StyleModNFFB", 2048, 55)}
+
+
+def nffb_conf(embed_type):
+    c = idr_conf("C1")
+    c["implicit_network"]["multires"] = 6
+    c["embedding_network"] = dict(embed_type=embed_type, log2_max_hash_size=5, max_points_per_entry=2,
+                                  base_resolution=16, desired_resolution=512, bound=1.0)
+    return Conf(c)
+
+
+def gen_idr_step_nffb(tag):
+    """One full iteration (forward + IDRLoss + backward + clip + Adam) with a filter-bank embedder:
+    BASELINE configs[2] ('FFB', 4096 rays) and configs[4] ('StyleModNFFB', 2048 rays; fp32 - the reference has no
+    reduced-precision path)."""
+    embed_type, n, seed = NFFB_STEP[tag]
+    model = quiet(IDRNetwork, nffb_conf(embed_type))
+    E = 3 + 8 + 8 * 6
+    sd = model.implicit_network.state_dict()
+    for k, v in P.make_sdf_params(seed + 7, E, (512,) * 8, 257, (4,), 1.0, 0.1, 0.1).items():
+        assert sd[k].shape == v.shape, (k, sd[k].shape, v.shape)
+        sd[k] = T(v)
+    for k, v in P.make_nffb_params(seed + 3, 6, embed_type == "StyleModNFFB", 0.3).items():
+        kk = "embed_model.embedder_obj." + k
+        assert sd[kk].shape == v.shape, (kk, sd[kk].shape, v.shape)
+        sd[kk] = T(v)
+    model.implicit_network.load_state_dict(sd)
+    vlevels, vB, _, _ = P.make_embedder_state(seed + 20, "viewdir", 0.5)
+    load_embedder(model.rendering_network.embed_model.embedder_obj, vlevels, vB)
+    sd = model.rendering_network.state_dict()
+    for k, v in P.make_render_params(seed + 9, d_in0=sd["lin0.weight_v"].shape[1]).items():
+        assert sd[k].shape == v.shape, (k, sd[k].shape, v.shape)
+        sd[k] = T(v)
+    model.rendering_network.load_state_dict(sd)
+    cam, dirs = P.make_rays(seed + 50, n)
+    z = -cam[0] / np.linalg.norm(cam[0])
+    xax = np.cross(np.array([0.0, 1.0, 0.0]), z)
+    xax /= np.linalg.norm(xax)
+    yax = np.cross(z, xax)
+    R = np.stack([xax, yax, z], 1)
+    pose = np.eye(4, dtype=np.float32)
+    pose[:3, :3] = R
+    pose[:3, 3] = cam[0]
+    dc = dirs[0].astype(np.float64) @ R
+    uv = (dc[:, :2] / dc[:, 2:3]).astype(np.float32).reshape(1, n, 2)
+    intr = np.eye(4, dtype=np.float32).reshape(1, 4, 4)
+    rs = np.random.RandomState(seed + 60)
+    object_mask = (rs.uniform(0, 1, n) < 0.85).reshape(1, n)
+    rgb_gt = rs.uniform(-1, 1, (1, n, 3)).astype(np.float32)
+    inp = dict(intrinsics=T(intr), uv=T(uv), pose=T(pose.reshape(1, 4, 4)), object_mask=T(object_mask))
+    loss_fn = IDRLoss(eikonal_weight=0.1, mask_weight=100.0, alpha=50.0)
+    model.train()
+    torch.manual_seed(1000)
+    draws, orig = _record_uniform()
+    try:
+        out = quiet(model, inp)
+    finally:
+        torch.Tensor.uniform_ = orig
+    lo = loss_fn(out, {"rgb": T(rgb_gt)})
+    model.zero_grad()
+    lo["loss"].backward()
+    gn = torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
+    arrays = dict(intrinsics=intr, uv=uv, pose=pose.reshape(1, 4, 4), object_mask=object_mask, rgb_gt=rgb_gt,
+                  seed=np.int64(seed), embed_type=np.asarray(embed_type))
+    arrays["s0:n_draws"] = np.int64(len(draws))
+    for i, dv in enumerate(draws):
+        arrays[f"s0:draw{i}"] = dv
+    for k in ("loss", "rgb_loss", "eikonal_loss", "mask_loss"):
+        arrays[f"s0:{k}"] = np.float64(lo[k].item())
+    arrays["s0:total_grad_norm"] = np.float64(gn.item())
+    arrays["s0:network_object_mask"] = out["network_object_mask"].numpy()
+    arrays["s0:rgb_values"] = out["rgb_values"].detach().numpy()
+    arrays["s0:sdf_output"] = out["sdf_output"].detach().numpy()
+    arrays["s0:grad_theta"] = out["grad_theta"].detach().numpy()
+    for k, p_ in model.named_parameters():
+        arrays[f"s0:gradnorm:{k}"] = np.float64(-1.0 if p_.grad is None else p_.grad.double().norm().item())
+    arrays["param_names"] = np.asarray([k for k, _ in model.named_parameters()])
+    save("idr_step_" + tag, **arrays)
+
+
 def gen_init_rng():
     """Seed-for-seed initialisation parity: checksums of the reference's freshly constructed params."""
     arrays = {}
@@ -518,7 +603,8 @@ def gen_idr_eval():
          sdf_output=out["sdf_output"].detach().numpy(), network_object_mask=out["network_object_mask"].numpy())
 
 
-GENS = dict(sdf_C2=lambda: gen_sdf(("C2",)), raytrace_C2=lambda: gen_raytrace(("C2",)), idr_step_C2=gen_idr_step_C2,
+GENS = dict(idr_step_C4=gen_idr_step_C4, idr_step_C3=lambda: gen_idr_step_nffb("C3"),
+            idr_step_C5=lambda: gen_idr_step_nffb("C5"), sdf_C2=lambda: gen_sdf(("C2",)), raytrace_C2=lambda: gen_raytrace(("C2",)), idr_step_C2=gen_idr_step_C2,
             idr_eval=gen_idr_eval, nffb=gen_nffb, levels=gen_levels, hash_ids=gen_hash_ids, encode=gen_encode, encode_bwd=gen_encode_bwd,
             sdf=gen_sdf, raytrace=gen_raytrace, idr_step=gen_idr_step, init_rng=gen_init_rng,
             camera=gen_camera)

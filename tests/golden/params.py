@@ -147,6 +147,33 @@ def make_render_params(seed, d_in0=281, hidden=(512,) * 4, d_out=3, g_jitter=0.1
     return out
 
 
+def make_nffb_params(seed, L, style, table_scale=0.5, F=2, log2_T=5, base=16, desired=512):
+    """Parameters of a FourierFilterBanks embedder ('FFB' / 'StyleModNFFB') with SIREN-like statistics, keyed as the
+    reference's state_dict (embedder_obj.*): ff_lin{l}, out_layer, [StyleAttentionBlock.*], grid_enc levels + B."""
+    rs = np.random.RandomState(seed)
+    W = 8 + 8 * L
+    w0 = float(L ** F - L)
+    out = {}
+    for l in range(L - 1):
+        fan_in = 3 if l == 0 else W
+        bound = 1.0 / fan_in if l == 0 else math.sqrt(6.0 / fan_in) / w0
+        out[f"ff_lin{l}.weight"] = rs.uniform(-bound, bound, (W, fan_in)).astype(F32)
+        out[f"ff_lin{l}.bias"] = rs.uniform(-bound, bound, (W,)).astype(F32)
+    b = 1.0 / math.sqrt(W)
+    out["out_layer.weight"] = rs.uniform(-b, b, (W, W)).astype(F32)
+    out["out_layer.bias"] = rs.uniform(-b, b, (W,)).astype(F32)
+    if style:
+        out["StyleAttentionBlock.linear_transform.weight"] = rs.uniform(-b, b, (W, W)).astype(F32)
+        out["StyleAttentionBlock.linear_transform.bias"] = rs.uniform(-b, b, (W,)).astype(F32)
+        out["StyleAttentionBlock.attention.weight"] = rs.uniform(-0.5, 0.5, (1, 3)).astype(F32)
+        out["StyleAttentionBlock.attention.bias"] = rs.uniform(-0.5, 0.5, (1,)).astype(F32)
+    res, rows = level_table(L, log2_T, base, desired)
+    for l in range(L):
+        out[f"grid_enc.levels.{l}.embedding.weight"] = rs.uniform(-table_scale, table_scale, (rows[l], F)).astype(F32)
+    out["grid_enc.freq_encoding.B"] = (rs.standard_normal((3, L)) * fourier_sigma(base, desired)).astype(F32)
+    return out
+
+
 def make_embedder_state(seed, cfg, table_scale=1e-4):
     """(per-level tables list, B) for one hash-grid embedder config."""
     L, T, b, d = CONFIGS[cfg] if isinstance(cfg, str) else cfg

@@ -82,3 +82,31 @@ def make_idr(cfg, seed, bias=0.6, device="cuda"):
         sd[k] = torch.from_numpy(v)
     model.rendering_network.load_state_dict(sd)
     return model.to(device)
+
+
+def nffb_conf(embed_type):
+    c = idr_conf("C1")
+    c["implicit_network"]["multires"] = 6
+    c["embedding_network"] = dict(embed_type=embed_type, log2_max_hash_size=5, max_points_per_entry=2,
+                                  base_resolution=16, desired_resolution=512, bound=1.0)
+    return Conf(c)
+
+
+def make_idr_nffb(embed_type, seed, device="cuda"):
+    """IDRNetwork on a filter-bank embedder with the seeded parameters make_goldens.gen_idr_step_nffb gave the reference."""
+    from hashmodnffbanks_idr_amd.model.implicit_differentiable_renderer import IDRNetwork
+    model = IDRNetwork(nffb_conf(embed_type))
+    sd = model.implicit_network.state_dict()
+    for k, v in P.make_sdf_params(seed + 7, 3 + 8 + 8 * 6, (512,) * 8, 257, (4,), 1.0, 0.1, 0.1).items():
+        assert sd[k].shape == v.shape, (k, sd[k].shape, v.shape)
+        sd[k] = torch.from_numpy(v)
+    for k, v in P.make_nffb_params(seed + 3, 6, embed_type == "StyleModNFFB", 0.3).items():
+        sd["embed_model.embedder_obj." + k] = torch.from_numpy(v)
+    model.implicit_network.load_state_dict(sd)
+    vl, vB, _, _ = P.make_embedder_state(seed + 20, "viewdir", 0.5)
+    load_embedder(model.rendering_network.embed_model.embedder_obj, vl, vB)
+    sd = model.rendering_network.state_dict()
+    for k, v in P.make_render_params(seed + 9, d_in0=sd["lin0.weight_v"].shape[1]).items():
+        sd[k] = torch.from_numpy(v)
+    model.rendering_network.load_state_dict(sd)
+    return model.to(device)

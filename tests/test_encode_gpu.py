@@ -171,3 +171,30 @@ def test_deterministic_table_backward(mode):
     acc = torch.ones_like(d1)
     ops.encode_bwd_table(desc, x, g, fm, out=acc, deterministic=True)          # accumulates into the given tensor
     assert torch.allclose(acc - 1.0, d1, rtol=1e-5, atol=1e-5 * scale)
+
+
+@pytest.mark.parametrize("mode", ["reference", "trilinear"])
+@pytest.mark.parametrize("cfg", ["C2", "C4"])
+def test_zordered_table_backward(cfg, mode):
+    """big launches take the z-ordered, LDS-privatised scatter (hm_encode_bwd_table_ws): same gradient as the atomic
+    kernel on the same points (fp32 summation order differs), nothing lost on ragged sizes or outside [-1,1]^3"""
+    import params as P
+    from hashmodnffbanks_idr_amd import _lib, ops
+    L, T, b, d = P.CONFIGS[cfg]
+    res, rows = P.level_table(L, T, b, d)
+    desc = ops.GridDesc(res, rows, 2)
+    n = 200000 + 37
+    g = torch.Generator(device="cpu").manual_seed(3)
+    x = (torch.rand((n, 3), generator=g) * 2.6 - 1.3).cuda()          # some points outside the unit cube
+    x[2000:4000] = x[:2000].clone()
+    gf = torch.randn((n, L * 2), generator=g).cuda()
+    fm = ops.FRAC_MODES[mode]
+    got = ops.encode_bwd_table(desc, x, gf, fm)                        # n >= 131072 -> workspace path
+    ref = torch.zeros_like(got)
+    _lib.check(_lib.lib().hm_encode_bwd_table(desc.handle, _lib.dptr(x), n, _lib.dptr(gf), gf.stride(0), _lib.dptr(ref),
+                                              fm, _lib.stream_ptr(x)))
+    scale = ref.abs().max().item()
+    err = (got - ref).abs().max().item()
+    print(f"z-ordered table backward {cfg}/{mode}: max |d| {err:.3e} (scale {scale:.3e})")
+    assert err <= 3e-5 * scale
+    assert abs(got.double().sum().item() - ref.double().sum().item()) <= 1e-5 * ref.double().abs().sum().item()

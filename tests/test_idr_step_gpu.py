@@ -9,7 +9,7 @@ from helpers import make_idr
 
 pytestmark = pytest.mark.gpu
 
-CASES = [("C1", 3), ("C2", 1)]
+CASES = [("C1", 3), ("C2", 1), ("C4", 1)]      # C4: BASELINE configs[3] per-GPU shape (T = 2^22)
 
 
 def _model(g, cfg):
@@ -28,7 +28,7 @@ def _close_mostly(a, b, rtol, atol, max_bad=0.005, what=""):
     assert bad.mean() <= max_bad, f"{what}: {bad.sum()} / {bad.size} outside tolerance, max {err.max()}"
 
 
-def _check_first_step(g, out, lo, gn, model, n_rays, tag):
+def _check_first_step(g, out, lo, gn, model, n_rays, tag, max_flips=2):
     """Everything the reference recorded for its first iteration.  Rays whose network_object_mask differs from the
     reference's (a threshold decision on SDF values that differ in the last bits; at most 2 allowed) are masked
     out of the per-ray comparisons and widen the tolerance of the sums they enter - the checks ALWAYS run."""
@@ -36,7 +36,7 @@ def _check_first_step(g, out, lo, gn, model, n_rays, tag):
     flip = out["network_object_mask"].cpu().numpy() != ref_mask
     mism = int(flip.sum())
     print(f"[{tag}] network_object_mask mismatches: {mism} / {ref_mask.size}")
-    assert mism <= 2, f"{mism} network_object_mask mismatches"
+    assert mism <= max_flips, f"{mism} network_object_mask mismatches"
     keep = ~flip
     per_ray = mism / float(n_rays)
     for k, share in (("loss", 8.0), ("rgb_loss", 4.0), ("eikonal_loss", 2.0), ("mask_loss", 8.0)):
@@ -49,22 +49,28 @@ def _check_first_step(g, out, lo, gn, model, n_rays, tag):
     assert abs(gn - ref_gn) <= (2e-3 + 8.0 * per_ray) * ref_gn, (gn, ref_gn)
     n_eik = n_rays // 2
     keep_g = np.concatenate([np.ones(n_eik, bool), keep])      # grad_theta rows: eikonal samples, then the ray points
-    _close_mostly(out["sdf_output"].detach().cpu().numpy()[keep], g["s0:sdf_output"][keep], 1e-4, 2e-5,
+    # (1 % outliers allowed on the per-ray SDF: 0.2 - 0.54 % of the ray points of the T = 2^19 / 2^22 grids sit close
+    #  enough to a voxel face of some level for a last-bit difference of the point to change its voxel)
+    _close_mostly(out["sdf_output"].detach().cpu().numpy()[keep], g["s0:sdf_output"][keep], 1e-4, 2e-5, max_bad=0.01,
                   what="sdf_output")
     _close_mostly(out["grad_theta"].detach().cpu().numpy()[keep_g], g["s0:grad_theta"][keep_g], 1e-3, 2e-4,
                   what="grad_theta")
     _close_mostly(out["rgb_values"].detach().cpu().numpy()[keep], g["s0:rgb_values"][keep], 1e-3, 2e-4,
                   what="rgb_values")
     emb = model.implicit_network.embed_model.embedder_obj
+    emb = getattr(emb, "grid_enc", emb)          # filter-bank embedders own a hash grid (grid_enc)
     off = emb.desc.row_off
     gtol = 5e-3 + 8.0 * per_ray
     worst = 0.0
     for name, p in model.named_parameters():
-        if name.endswith("implicit_network.embed_model.embedder_obj.table"):
+        if name.startswith("implicit_network.") and name.endswith(".table"):
+            stem = name[:-len("table")]
             for l in range(emb.n_levels):
-                ref = float(g["s0:gradnorm:implicit_network.embed_model.embedder_obj.levels."
-                              f"{l}.embedding.weight"])
-                got = p.grad[int(off[l]):int(off[l + 1])].double().norm().item()
+                ref = float(g[f"s0:gradnorm:{stem}levels.{l}.embedding.weight"])
+                got = 0.0 if p.grad is None else p.grad[int(off[l]):int(off[l + 1])].double().norm().item()
+                if ref <= 0:
+                    assert got == 0.0, (name, l, got)        # a level that never reaches the output (filter banks)
+                    continue
                 worst = max(worst, abs(got - ref) / (ref + 1e-30))
                 assert abs(got - ref) <= gtol * ref + 1e-9, (name, l, got, ref)
         elif name.endswith("embedder_obj.table"):
@@ -161,6 +167,46 @@ def test_graphed_step_C2_matches_reference(golden):
     st = model.ray_tracer.last_stats
     assert st["unfinished"] == 0 and st.get("nonfinite", 0) == 0
     _check_first_step(g, out, lo, float(opt.last_grad_norm.item()), model, n_rays, "C2 captured graph")
+
+
+@pytest.mark.parametrize("tag", ["C3", "C5"])
+@pytest.mark.parametrize("graphed", [False, True])
+def test_idr_step_filter_bank_configs(golden, tag, graphed):
+    """BASELINE configs[2] ('FFB', 4096 rays) and configs[4] ('StyleModNFFB', 2048 rays; fp32): one full iteration
+    against the reference's recorded iteration - eager (dynamic shapes) and as the captured graph.  sin(30 .) in the
+    trunk amplifies last-bit differences of the embedding, so a few more rays than in the hash-grid configurations may
+    land on the other side of a tracing threshold (<= 0.3 % allowed)."""
+    from helpers import make_idr_nffb
+    from hashmodnffbanks_idr_amd.model.loss import IDRLoss
+    from hashmodnffbanks_idr_amd.training.graph_step import GraphedTrainStep
+    from hashmodnffbanks_idr_amd.training.optim import ClipAdam
+    g = golden(f"idr_step_{tag}")
+    model = make_idr_nffb(str(g["embed_type"]), int(g["seed"]))
+    model.train()
+    inp = {k: torch.from_numpy(g[k]).cuda() for k in ("intrinsics", "uv", "pose", "object_mask")}
+    gt = {"rgb": torch.from_numpy(g["rgb_gt"]).cuda()}
+    n_rays = g["uv"].shape[1]
+    loss_fn = IDRLoss(eikonal_weight=0.1, mask_weight=100.0, alpha=50.0)
+    flips = max(2, int(0.003 * n_rays))
+    if graphed:
+        opt = ClipAdam(model.parameters(), lr=0.0, max_norm=1.0)
+        stepper = GraphedTrainStep(model, loss_fn, opt, warmup=2)
+        for _ in range(4):
+            torch.manual_seed(1000)
+            out, lo = stepper.step(inp, gt)
+        assert stepper.g_fb is not None, "graph capture fell back to eager"
+        torch.cuda.synchronize()
+        st = model.ray_tracer.last_stats
+        assert st["unfinished"] == 0 and st["nonfinite"] == 0
+        _check_first_step(g, out, lo, float(opt.last_grad_norm.item()), model, n_rays, f"{tag} captured graph", flips)
+    else:
+        torch.manual_seed(1000)
+        out = model(inp)
+        lo = loss_fn(out, gt)
+        model.zero_grad()
+        lo["loss"].backward()
+        gn = torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
+        _check_first_step(g, out, lo, gn.item(), model, n_rays, f"{tag} eager", flips)
 
 
 def test_idr_eval_forward(golden):
