@@ -1,0 +1,210 @@
+// hm_encode_dx.hip - input-gradient kernels of the hash-grid encoder for frac_mode = trilinear (opt-in, non-parity
+// mode: the reference's interpolation weights are degenerate, xf = x - x.float() == 0 at hashGridEmbedding.py:86, so
+// there d(features)/dx is identically zero and none of this runs).
+//
+// With xs_d = x_d * res, t_d = xs_d - floor(xs_d) and corner bits b_d in {0,1}:
+//   feat[l,f]          = sum_c  w_x w_y w_z T[id_c][f],                w_d = b_d ? t_d : 1 - t_d
+//   d feat / d x_d     = res   * sum_c s_d      prod_{e != d} w_e  T,  s_d = b_d ? +1 : -1
+//   d2 feat / dx_d dx_e = res^2 * sum_c s_d s_e  w_k               T   (d != e, k the third axis; 0 for d == e)
+// The three products IDR's eikonal / normal terms need (ImplicitNetwork.gradient differentiates the embedding with
+// create_graph=True, implicit_differentiable_renderer.py:116-127) are
+//   hm_encode_bwd_input     gx[i,:]   = J_i^T d_feat[i,:]                   (and, given a, its derivative along a)
+//   hm_encode_jvp           out[i,:]  = J_i a[i,:]                          (backward of gx w.r.t. d_feat)
+//   hm_encode_bwd_table_jvp d_table  += scatter of (dJ_i/dT . a) d_feat     (backward of gx w.r.t. the table)
+// where J_i = d feat[i,:] / d x[i,:]  [L*F, 3].  Inside a voxel the formulas are exact; across voxel faces the
+// features are continuous and piecewise trilinear, their gradient jumps - like any trilinear grid.
+#include "hm_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+struct CornerJet {
+    float w[3];    // per-axis interpolation weight of this corner
+    float s[3];    // its derivative sign
+    uint32_t id;   // row inside the level
+    float r;       // level resolution
+};
+
+__device__ __forceinline__ CornerJet corner_jet(const HmLevels &lv, int l, int c, float x0, float x1, float x2) {
+    CornerJet j;
+    const int32_t res = lv.res[l];
+    const float xin[3] = {x0, x1, x2};
+    uint32_t u[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float xs = __fmul_rn(xin[d], (float)res);
+        const float fl = floorf(xs);
+        const float t = __fsub_rn(xs, fl);
+        const int bit = (c >> d) & 1;
+        u[d] = (uint32_t)(int32_t)fl + (uint32_t)bit;
+        j.w[d] = bit ? t : __fsub_rn(1.0f, t);
+        j.s[d] = bit ? 1.0f : -1.0f;
+    }
+    j.id = hm_mod_rows(hm_hash3(u[0], u[1], u[2]), lv.rows[l], lv.magic[l]);
+    j.r = (float)res;
+    return j;
+}
+
+// q = sum_d a_d * d(w_x w_y w_z)/dx_d
+__device__ __forceinline__ float jet_dot(const CornerJet &j, float a0, float a1, float a2) {
+    return j.r * (a0 * j.s[0] * j.w[1] * j.w[2] + a1 * j.s[1] * j.w[0] * j.w[2] + a2 * j.s[2] * j.w[0] * j.w[1]);
+}
+
+__device__ __forceinline__ float sum8(float v) {   // over the 8 corner lanes of one (point, level)
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    return v;
+}
+
+// out[i, l*F + f] = sum_c q_c T[id_c][f]; one lane per (point, level, corner)
+__global__ __launch_bounds__(kThreads) void encode_jvp_kernel(HmLevels lv, const float *__restrict__ x, int64_t n,
+                                                              const float *__restrict__ table,
+                                                              const float *__restrict__ a, float *__restrict__ out,
+                                                              int64_t out_stride) {
+    const int L = lv.L, F = lv.F;
+    const int64_t gid = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int c = (int)(gid & 7);
+    const int64_t pl = gid >> 3;
+    int64_t i = pl / L;
+    const int l = (int)(pl - i * L);
+    const bool live = i < n;
+    if (!live) i = n - 1;               // keep the whole wave in the shuffles
+    const CornerJet j = corner_jet(lv, l, c, x[i * 3], x[i * 3 + 1], x[i * 3 + 2]);
+    const float q = jet_dot(j, a[i * 3], a[i * 3 + 1], a[i * 3 + 2]);
+    const float *row = table + ((uint64_t)lv.row_off[l] + j.id) * F;
+    for (int f = 0; f < F; ++f) {
+        const float v = sum8(q * row[f]);
+        if (live && c == 0) out[i * out_stride + l * F + f] = v;
+    }
+}
+
+// d_table[id_c][f] += q_c * d_feat[i, l*F + f]
+__global__ __launch_bounds__(kThreads) void encode_bwd_table_jvp_kernel(HmLevels lv, const float *__restrict__ x,
+                                                                        int64_t n, const float *__restrict__ a,
+                                                                        const float *__restrict__ d_feat,
+                                                                        int64_t d_feat_stride,
+                                                                        float *__restrict__ d_table) {
+    const int L = lv.L, F = lv.F;
+    const int64_t gid = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int c = (int)(gid & 7);
+    const int64_t pl = gid >> 3;
+    const int64_t i = pl / L;
+    const int l = (int)(pl - i * L);
+    if (i >= n) return;
+    const CornerJet j = corner_jet(lv, l, c, x[i * 3], x[i * 3 + 1], x[i * 3 + 2]);
+    const float q = jet_dot(j, a[i * 3], a[i * 3 + 1], a[i * 3 + 2]);
+    if (q == 0.0f) return;
+    const float *g = d_feat + i * d_feat_stride + l * F;
+    float *row = d_table + ((uint64_t)lv.row_off[l] + j.id) * F;
+    for (int f = 0; f < F; ++f) atomicAdd(row + f, q * g[f]);
+}
+
+// gx[i,d] = sum_{l,c} (d_feat[i,l,:] . T[id_c]) * coefficient_d; 8 lanes per point (one per corner) walk the levels,
+// so the sum order is fixed (no atomics).  SECOND: coefficient_e = sum_{d != e} a_d * d2(w_x w_y w_z)/dx_d dx_e.
+template <bool SECOND>
+__global__ __launch_bounds__(kThreads) void encode_bwd_input_kernel(HmLevels lv, const float *__restrict__ x,
+                                                                    int64_t n, const float *__restrict__ table,
+                                                                    const float *__restrict__ d_feat,
+                                                                    int64_t d_feat_stride,
+                                                                    const float *__restrict__ a,
+                                                                    float *__restrict__ gx) {
+    const int L = lv.L, F = lv.F;
+    const int64_t gid = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int c = (int)(gid & 7);
+    int64_t i = gid >> 3;
+    const bool live = i < n;
+    if (!live) i = n - 1;
+    const float x0 = x[i * 3], x1 = x[i * 3 + 1], x2 = x[i * 3 + 2];
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+    if (SECOND) {
+        a0 = a[i * 3]; a1 = a[i * 3 + 1]; a2 = a[i * 3 + 2];
+    }
+    float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f;
+    for (int l = 0; l < L; ++l) {
+        const CornerJet j = corner_jet(lv, l, c, x0, x1, x2);
+        const float *row = table + ((uint64_t)lv.row_off[l] + j.id) * F;
+        const float *g = d_feat + i * d_feat_stride + l * F;
+        float val = 0.0f;
+        for (int f = 0; f < F; ++f) val += g[f] * row[f];
+        if (!SECOND) {
+            val *= j.r;
+            g0 += val * j.s[0] * j.w[1] * j.w[2];
+            g1 += val * j.s[1] * j.w[0] * j.w[2];
+            g2 += val * j.s[2] * j.w[0] * j.w[1];
+        } else {
+            val *= j.r * j.r;
+            const float s01 = j.s[0] * j.s[1] * j.w[2], s02 = j.s[0] * j.s[2] * j.w[1], s12 = j.s[1] * j.s[2] * j.w[0];
+            g0 += val * (a1 * s01 + a2 * s02);
+            g1 += val * (a0 * s01 + a2 * s12);
+            g2 += val * (a0 * s02 + a1 * s12);
+        }
+    }
+    g0 = sum8(g0); g1 = sum8(g1); g2 = sum8(g2);
+    if (live && c == 0) {
+        gx[i * 3] = g0; gx[i * 3 + 1] = g1; gx[i * 3 + 2] = g2;
+    }
+}
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+bool grid_ok(int64_t threads, int64_t &grid) {
+    grid = (threads + kThreads - 1) / kThreads;
+    return grid <= 0x7fffffffLL;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hm_encode_bwd_input(const hm_grid_desc *desc, const float *x, int64_t n, const float *table, const float *d_feat,
+                        int64_t d_feat_stride, const float *a, float *gx, void *stream) {
+    HM_CHECK_ARG(desc != nullptr, "hm_encode_bwd_input: desc is NULL");
+    HM_CHECK_ARG(n >= 0, "hm_encode_bwd_input: n < 0");
+    HM_CHECK_ARG(d_feat_stride >= desc->lv.L * desc->lv.F, "hm_encode_bwd_input: d_feat_stride < L*F");
+    if (n == 0) return HM_OK;
+    HM_CHECK_ARG(x && table && d_feat && gx, "hm_encode_bwd_input: NULL pointer");
+    int64_t grid;
+    HM_CHECK_ARG(grid_ok(n * 8, grid), "hm_encode_bwd_input: n too large for one launch");
+    if (a)
+        hipLaunchKernelGGL(encode_bwd_input_kernel<true>, dim3((unsigned)grid), dim3(kThreads), 0, as_stream(stream),
+                           desc->lv, x, n, table, d_feat, d_feat_stride, a, gx);
+    else
+        hipLaunchKernelGGL(encode_bwd_input_kernel<false>, dim3((unsigned)grid), dim3(kThreads), 0, as_stream(stream),
+                           desc->lv, x, n, table, d_feat, d_feat_stride, a, gx);
+    HM_CHECK_LAUNCH("hm_encode_bwd_input");
+    return HM_OK;
+}
+
+int hm_encode_jvp(const hm_grid_desc *desc, const float *x, int64_t n, const float *table, const float *a, float *out,
+                  int64_t out_stride, void *stream) {
+    HM_CHECK_ARG(desc != nullptr, "hm_encode_jvp: desc is NULL");
+    HM_CHECK_ARG(n >= 0, "hm_encode_jvp: n < 0");
+    HM_CHECK_ARG(out_stride >= desc->lv.L * desc->lv.F, "hm_encode_jvp: out_stride < L*F");
+    if (n == 0) return HM_OK;
+    HM_CHECK_ARG(x && table && a && out, "hm_encode_jvp: NULL pointer");
+    int64_t grid;
+    HM_CHECK_ARG(grid_ok(n * desc->lv.L * 8, grid), "hm_encode_jvp: n too large for one launch");
+    hipLaunchKernelGGL(encode_jvp_kernel, dim3((unsigned)grid), dim3(kThreads), 0, as_stream(stream), desc->lv, x, n,
+                       table, a, out, out_stride);
+    HM_CHECK_LAUNCH("hm_encode_jvp");
+    return HM_OK;
+}
+
+int hm_encode_bwd_table_jvp(const hm_grid_desc *desc, const float *x, int64_t n, const float *a, const float *d_feat,
+                            int64_t d_feat_stride, float *d_table, void *stream) {
+    HM_CHECK_ARG(desc != nullptr, "hm_encode_bwd_table_jvp: desc is NULL");
+    HM_CHECK_ARG(n >= 0, "hm_encode_bwd_table_jvp: n < 0");
+    HM_CHECK_ARG(d_feat_stride >= desc->lv.L * desc->lv.F, "hm_encode_bwd_table_jvp: d_feat_stride < L*F");
+    if (n == 0) return HM_OK;
+    HM_CHECK_ARG(x && a && d_feat && d_table, "hm_encode_bwd_table_jvp: NULL pointer");
+    int64_t grid;
+    HM_CHECK_ARG(grid_ok(n * desc->lv.L * 8, grid), "hm_encode_bwd_table_jvp: n too large for one launch");
+    hipLaunchKernelGGL(encode_bwd_table_jvp_kernel, dim3((unsigned)grid), dim3(kThreads), 0, as_stream(stream),
+                       desc->lv, x, n, a, d_feat, d_feat_stride, d_table);
+    HM_CHECK_LAUNCH("hm_encode_bwd_table_jvp");
+    return HM_OK;
+}
+
+}  // extern "C"

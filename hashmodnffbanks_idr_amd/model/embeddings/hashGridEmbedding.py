@@ -8,7 +8,8 @@ Differences in mechanism (not behaviour):
     reference keys ``levels.{l}.embedding.weight`` and ``freq_encoding.B``;
   * ``frac_mode="reference"`` (default) reproduces the reference's degenerate interpolation
     weights (xf = x - x.float() == 0, hashGridEmbedding.py:86); ``"trilinear"`` is an opt-in,
-    non-parity mode.
+    non-parity mode with real interpolation weights, differentiable w.r.t. x to second order
+    (csrc/hm_encode_dx.hip), so the eikonal / normal terms train it.
 """
 import math
 

@@ -142,19 +142,21 @@ class _HashFeatures(torch.autograd.Function):
     [N,E] row [x|sin|cos|features] (B given; only the feature columns carry gradient).
     Differentiable to any order w.r.t. the table (the op is linear in it).  In reference frac mode
     d/dx of the hash features is identically zero, exactly as in the reference where
-    xf = x - x.float() kills the interpolation weights (hashGridEmbedding.py:86)."""
+    xf = x - x.float() kills the interpolation weights (hashGridEmbedding.py:86); in trilinear mode
+    d/dx is the node _HashInputGrad (differentiable once more)."""
 
     @staticmethod
     def forward(ctx, x, table, B, desc, frac_mode, collector=None):
         ctx.desc, ctx.frac_mode, ctx.collector = desc, frac_mode, collector
         ctx.hoff = 0 if B is None else 3 + 2 * desc.L
         ctx.save_for_backward(x)
+        ctx.table = table if (frac_mode != 0 and ctx.needs_input_grad[0]) else None   # d/dx gathers the table again
         return encode_fwd(desc, x, table, B, frac_mode, hash_only=B is None)
 
     @staticmethod
     def backward(ctx, d_out):
         (x,) = ctx.saved_tensors
-        d_table = None
+        d_table = d_x = None
         if ctx.needs_input_grad[1]:
             d_feat = d_out[:, ctx.hoff:] if ctx.hoff else d_out
             if ctx.collector is not None and ctx.collector.active:
@@ -168,8 +170,45 @@ class _HashFeatures(torch.autograd.Function):
             if ctx.hoff:
                 raise RuntimeError("internal: full-row encode node must not be used when x requires grad")
             if ctx.frac_mode != 0:
-                raise NotImplementedError("frac_mode='trilinear' has no d/dx kernel yet (non-parity mode)")
-        return None, d_table, None, None, None, None
+                d_x = _HashInputGrad.apply(x, ctx.table, d_out, ctx.desc)
+        return d_x, d_table, None, None, None, None
+
+
+class _HashInputGrad(torch.autograd.Function):
+    """gx = J(x)^T d_feat of the trilinear encoder (J = d features / d x) as a node of its own, so that
+    ImplicitNetwork.gradient(create_graph=True) can be differentiated once more: the eikonal / normal terms' backward
+    arrives here as gg_x and leaves towards d_feat (J gg_x), the table and x (csrc/hm_encode_dx.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, table, d_feat, desc):
+        ctx.desc = desc
+        d_feat = _rowmajor(d_feat)
+        ctx.save_for_backward(x, table, d_feat)
+        gx = torch.empty_like(x)
+        check(lib().hm_encode_bwd_input(desc.handle, dptr(x), x.shape[0], dptr(table), dptr(d_feat), _ld(d_feat),
+                                        None, dptr(gx), stream_ptr(x)))
+        return gx
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gg_x):
+        x, table, d_feat = ctx.saved_tensors
+        desc, n = ctx.desc, x.shape[0]
+        gg_x = gg_x.contiguous()
+        d_x = d_table = d_dfeat = None
+        if ctx.needs_input_grad[0]:
+            d_x = torch.empty_like(x)
+            check(lib().hm_encode_bwd_input(desc.handle, dptr(x), n, dptr(table), dptr(d_feat), _ld(d_feat),
+                                            dptr(gg_x), dptr(d_x), stream_ptr(x)))
+        if ctx.needs_input_grad[1]:
+            d_table = torch.zeros_like(table)
+            check(lib().hm_encode_bwd_table_jvp(desc.handle, dptr(x), n, dptr(gg_x), dptr(d_feat), _ld(d_feat),
+                                                dptr(d_table), stream_ptr(x)))
+        if ctx.needs_input_grad[2]:
+            d_dfeat = torch.empty((n, desc.L * desc.F), dtype=torch.float32, device=x.device)
+            check(lib().hm_encode_jvp(desc.handle, dptr(x), n, dptr(table), dptr(gg_x), dptr(d_dfeat),
+                                      d_dfeat.stride(0), stream_ptr(x)))
+        return d_x, d_table, d_dfeat, None
 
 
 class _HashScatter(torch.autograd.Function):

@@ -153,6 +153,11 @@ class PointGradExchange(_SparseExchange):
     node hands its contributions to add() instead of scattering them (ops._HashFeatures.backward)."""
 
     def __init__(self, emb):
+        if emb.frac_mode != "reference":
+            # the trilinear encoder sits on the x-graph: autograd.grad(e, x, create_graph=True) runs its table backward
+            # too (a custom Function cannot see that only d/dx was asked for) and would record bogus contributions;
+            # its second-order table term (hm_encode_bwd_table_jvp) is dense as well
+            raise NotImplementedError("PointGradExchange: frac_mode='trilinear' uses the dense table all-reduce")
         super().__init__(emb.table, 3 + emb.n_levels * emb.n_features)
         self.emb = emb
         emb.grad_collector = self

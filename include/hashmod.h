@@ -129,6 +129,23 @@ HM_API int hm_encode_bwd_table_sorted(const hm_grid_desc *desc, const int32_t *k
                                       int64_t n_keys, int corners, const float *d_feat, int64_t d_feat_stride,
                                       const float *weights, float *d_table, void *stream);
 
+/* ---- encoder input gradient (frac_mode = HM_FRAC_TRILINEAR only) ---------------------------------------------
+ * In the reference d(hash features)/dx is identically zero (xf = x - x.float() == 0, hashGridEmbedding.py:86), so
+ * autograd never runs anything here; these three entry points make the opt-in trilinear mode trainable under IDR's
+ * eikonal / normal terms, where ImplicitNetwork.gradient differentiates the embedding with create_graph=True
+ * (implicit_differentiable_renderer.py:116-127).  J_i = d feat[i,:] / d x[i,:]  [L*F, 3], exact inside a voxel.
+ *   hm_encode_bwd_input      a == NULL: gx[i,:] = J_i^T d_feat[i,:]            (the embedding's backward w.r.t. x)
+ *                            a != NULL: gx[i,:] = d/dx ( a[i,:] . J_i^T d_feat[i,:] )   (its second-order term)
+ *   hm_encode_jvp            out[i,:] = J_i a[i,:]                              (backward of gx w.r.t. d_feat)
+ *   hm_encode_bwd_table_jvp  d_table += d/dT ( sum_i a[i,:] . J_i^T d_feat[i,:] )  (fp32 atomics, accumulates)
+ * x, a, gx [n,3]; d_feat / out rows of L*F floats with the given row stride.                                        */
+HM_API int hm_encode_bwd_input(const hm_grid_desc *desc, const float *x, int64_t n, const float *table,
+                               const float *d_feat, int64_t d_feat_stride, const float *a, float *gx, void *stream);
+HM_API int hm_encode_jvp(const hm_grid_desc *desc, const float *x, int64_t n, const float *table, const float *a,
+                         float *out, int64_t out_stride, void *stream);
+HM_API int hm_encode_bwd_table_jvp(const hm_grid_desc *desc, const float *x, int64_t n, const float *a,
+                                   const float *d_feat, int64_t d_feat_stride, float *d_table, void *stream);
+
 /* ---- fused SDF network forward (no grad) ---------------------------------------------------
  * Replaces ImplicitNetwork.forward evaluated under torch.no_grad()
  * (model/implicit_differentiable_renderer.py:89-113 + density_net.py:20-30), i.e. the `sdf`
