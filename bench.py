@@ -50,6 +50,7 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s ach
 MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
 SDF_MAC_PER_POINT = 1966592  # SURVEY.md 8a row A9 (independent of the embedding width)
 RAYS_PER_GPU = 2048
+LAZY_SAMPLER_HEAD = 16   # RayTracing.sampler_head of the product (model/ray_tracing.py); legs other than "lazy" use 0
 CFG = "C2"          # BASELINE.json configs[1]; `--gpus 8` defaults to configs[3] ("C4", T=2^22)
 
 
@@ -341,6 +342,7 @@ def _side_leg(cfg, device, bf16, steps=6, warmup=3):
     a = types.SimpleNamespace(no_graph=False, warmup=warmup, steps=steps, rays=rays)
     model = _build(cfg, device, 0.0)
     model.implicit_network.bf16_coarse_search = bool(bf16)
+    model.ray_tracer.sampler_head = 0      # like the headline: the reference's evaluation count
     inp, gt = synthetic_batch(1234, rays, device)
     torch.manual_seed(100)
     dt, stats, final_loss, mode = _run_leg(a, model, ClipAdam(model.parameters(), lr=0.0, max_norm=1.0),
@@ -415,8 +417,11 @@ def main():
                     help="eager reference-structured step (dynamic shapes) instead of the HIP-graph captured step")
     ap.add_argument("--torch-adam", action="store_true",
                     help="torch.nn.utils.clip_grad_norm_ + torch.optim.Adam instead of the fused training.optim.ClipAdam")
-    ap.add_argument("--legs", choices=["both", "fixed", "train"], default="both",
-                    help="fixed = section-8(d) workload (weights stay at geometric init; the headline); train = lr 1e-4")
+    ap.add_argument("--legs", choices=["both", "fixed", "train", "lazy"], default="both",
+                    help="fixed = section-8(d) workload (weights stay at geometric init, every sampler ray evaluates all "
+                         "n_steps samples like the reference; the headline); train = the same with lr 1e-4; lazy = fixed "
+                         "weights with the product's default lazy sampler (RayTracing.sampler_head = 16: samples past a "
+                         "ray's first sign change are not evaluated, outputs bit-identical); both = all three")
     ap.add_argument("--gather-log2n", type=int, default=22)
     ap.add_argument("--calib", default="1,0", help="gather_calib: lanes per 128-B block, byte stride between them")
     ap.add_argument("--bf16", type=int, default=-1,
@@ -487,11 +492,12 @@ def main():
     use_bf16 = (args.bf16 == 1) or (args.bf16 < 0 and cfg == "C5")
     legs = {}
     model = None
-    for leg, lr in (("fixed", 0.0), ("train", 1.0e-4)):
+    for leg, lr, sampler_head in (("fixed", 0.0, 0), ("train", 1.0e-4, 0), ("lazy", 0.0, LAZY_SAMPLER_HEAD)):
         if args.legs not in ("both", leg):
             continue
         model = _build(cfg, device, lr)
         model.implicit_network.bf16_coarse_search = use_bf16
+        model.ray_tracer.sampler_head = sampler_head
         reducer = None
         if world > 1 or os.environ.get("HM_DIST_FORCE") == "1":   # (HM_DIST_FORCE: single-rank RCCL rehearsal)
             # hash-table gradients travel as (point, feature-gradient) pairs (parallel.PointGradExchange, ~0.7 MB per
@@ -508,15 +514,15 @@ def main():
         dt, stats, final_loss, mode = _run_leg(args, model, make_opt(model, lr), loss_fn, reducer, inp, gt, world,
                                                device, rank)
         legs[leg] = {"value": round(args.rays * world * args.steps / dt, 1), "unit": "rays/s",
-                     "ms_per_step": round(dt / args.steps * 1e3, 3), "lr": lr, "sdf_evals_per_step": stats,
-                     "final_loss": round(final_loss, 6), "step": mode}
+                     "ms_per_step": round(dt / args.steps * 1e3, 3), "lr": lr, "sampler_head": sampler_head,
+                     "sdf_evals_per_step": stats, "final_loss": round(final_loss, 6), "step": mode}
         if leg == "fixed":
             head_model = model
     if "fixed" not in legs:
         head_model = model
 
     if rank == 0:
-        head = legs.get("fixed") or legs["train"]
+        head = legs.get("fixed") or legs.get("train") or legs["lazy"]
         line = {
             "metric": "rays/sec fwd+bwd (hash+SDF MLP)", "value": head["value"], "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -533,11 +539,21 @@ def main():
                                       if "fixed" in legs else ", lr 1e-4 (surface moves during the timed region)"),
                        "grid_config": cfg, "rays_per_gpu": args.rays, "global_rays": args.rays * world,
                        "parallelism": f"ray-sharded dp{world}" if world > 1 else "single GPU",
-                       "step": head["step"], "sdf_evals_per_step": head["sdf_evals_per_step"]},
+                       "step": head["step"],
+                       "sampler": ("all n_steps samples of every unconverged ray are evaluated, as in the reference "
+                                   "(ray_tracing.py:189-249)" if head["sampler_head"] == 0 else
+                                   f"lazy: first pass over samples 0..{head['sampler_head'] - 1} + the last, second pass "
+                                   "for rays without a sign change there; outputs bit-identical to the single pass"),
+                       "sdf_evals_per_step": head["sdf_evals_per_step"]},
             "final_loss": head["final_loss"],
         }
         if "fixed" in legs and "train" in legs:
             line["train_leg"] = legs["train"]
+        if "lazy" in legs and head is not legs["lazy"]:
+            # same iteration, same weights, same outputs (tests/test_raytrace_gpu.py::test_lazy_sampler_equals_single_pass);
+            # the product default.  Reported beside the headline because SURVEY.md 8(d) characterises the workload by
+            # the reference's evaluation count (~123 per ray), which the lazy sampler undercuts.
+            line["lazy_sampler_leg"] = legs["lazy"]
         if not args.no_extras and cfg in NFFB_CONFIGS:
             line["cpu_baseline"] = None      # (the torch-CPU port covers the hash-grid embedder only)
         elif not args.no_extras:

@@ -86,7 +86,8 @@ class AdamTensor(C.Structure):
 class TraceCfg(C.Structure):
     _fields_ = [("object_bounding_sphere", C.c_float), ("sdf_threshold", C.c_float), ("line_search_step", C.c_double),
                 ("line_step_iters", C.c_int32), ("sphere_tracing_iters", C.c_int32), ("n_steps", C.c_int32),
-                ("n_secant_steps", C.c_int32), ("training", C.c_int32), ("coarse_bf16", C.c_int32)]
+                ("n_secant_steps", C.c_int32), ("training", C.c_int32), ("coarse_bf16", C.c_int32),
+                ("sampler_head", C.c_int32)]
 
 
 class NffbDesc(C.Structure):

@@ -32,6 +32,9 @@ enum : int32_t {  // counters (device int32 array)
     C_BIG_PTS = 73,      // points of the one big SDF launch: sampler points followed by closest-approach points
     C_NONFINITE = 72,    // SDF values consumed by the search that were NaN / Inf (must be 0: a NaN fails every
                          // `sdf > threshold` test, so the ray would silently count as converged where it stands)
+    C_NSAMP2 = 74,       // lazy sampler: rays whose first sign change is not among the head samples
+    C_HEAD_PTS = 75,     // points of the sampler's first pass (= where the closest-approach values start)
+    C_TAIL_PTS = 76,     // lazy sampler: points of the second pass
     C_COUNT = 80
 };
 
@@ -41,6 +44,7 @@ struct TraceWs {
     float *t_s, *t_e, *t_min, *t_max, *cur_s, *cur_e, *nxt_s, *nxt_e;  // [N]
     float *z_lo, *z_hi, *v_lo, *v_hi, *z;                               // [N] secant state by secant slot
     int32_t *slot_s, *slot_e, *list_samp, *list_sec, *list_sel;          // [N]
+    int32_t *tail_slot;      // [N] by sampler slot: index in the second pass, -1 = resolved by the head samples
     uint8_t *live_s, *live_e, *stage, *it, *k, *is_samp;                // [N]
     float *pts;    // [cap,3]
     float *vals;   // [cap]
@@ -64,6 +68,9 @@ struct TraceArgs {
     float thr;
     float back[4];           // (1 - line_search_step) / 2^k, formed in double on the host
     int32_t ls_iters, max_it, n_steps, n_secant, training;
+    int32_t head;            // lazy sampler: samples 0..head-1 and n_steps-1 form the first pass (0 = all in one pass)
+    int64_t tail_off;        // lazy sampler: where the second pass starts in pts / vals (host-known: the buffers are
+                             // sized for 2 * N * n_steps points)
 };
 
 __device__ __forceinline__ void along(const TraceArgs &a, int64_t i, float t, float &px, float &py, float &pz) {
@@ -199,20 +206,26 @@ __global__ __launch_bounds__(kTB) void trace_finalize_kernel(TraceArgs a) {
 // n_steps samples along every listed ray: t = lo + f*(hi - lo)  (ray_tracing.py:198-206, 277-286)
 // c_base >= 0: the points are appended behind the cnt[c_base] points already in the buffer (one SDF launch then
 // evaluates both sets); cnt[C_BIG_PTS] receives the total.
+//
+// Lazy sampler (a.head > 0): the reference reads, of a sampler ray's n_steps values, only those up to its FIRST negative
+// sample (argmin of sign * (n, n-1, ..), ray_tracing.py:212-218, plus the sample before it - or the last one when the
+// first sample is negative - for the secant bracket, :238-243) unless the ray falls back to the minimal sample
+// (:221-226), which needs all of them.  per_ray < n_steps selects the first pass: samples 0..head-1 and n_steps-1.
 __global__ __launch_bounds__(kTB) void ray_samples_kernel(TraceArgs a, const int32_t *list, int c_n, int c_npts,
                                                           const float *lo_arr, const float *hi_arr,
-                                                          const float *fr, int c_base) {
+                                                          const float *fr, int c_base, int per_ray) {
     const int64_t gid = (int64_t)blockIdx.x * kTB + threadIdx.x;
     const TraceWs &w = a.w;
     const int32_t n_list = w.cnt[c_n];
     const int64_t base = c_base >= 0 ? w.cnt[c_base] : 0;
     if (gid == 0) {
-        w.cnt[c_npts] = n_list * a.n_steps;
-        w.cnt[C_BIG_PTS] = (int32_t)base + n_list * a.n_steps;
+        w.cnt[c_npts] = n_list * per_ray;
+        w.cnt[C_BIG_PTS] = (int32_t)base + n_list * per_ray;
     }
-    const int64_t m = gid / a.n_steps;
+    const int64_t m = gid / per_ray;
     if (m >= n_list) return;
-    const int s = (int)(gid - m * a.n_steps);
+    int s = (int)(gid - m * per_ray);
+    if (per_ray < a.n_steps && s == per_ray - 1) s = a.n_steps - 1;
     const int64_t i = list[m];
     const float lo = lo_arr[i], hi = hi_arr[i];
     const float t = __fadd_rn(lo, __fmul_rn(fr[s], __fsub_rn(hi, lo)));
@@ -227,6 +240,42 @@ __device__ __forceinline__ float secant_z(float v_lo, float v_hi, float z_lo, fl
     return __fadd_rn(__fdiv_rn(__fmul_rn(-v_lo, __fsub_rn(z_hi, z_lo)), __fsub_rn(v_hi, v_lo)), z_lo);
 }
 
+// lazy sampler, between the passes: a ray is resolved by its head samples iff one of them is negative and the ray is
+// inside the object mask; every other ray joins the second pass (samples head..n_steps-2)
+__global__ __launch_bounds__(kTB) void sampler_head_kernel(TraceArgs a) {
+    const int64_t m = (int64_t)blockIdx.x * kTB + threadIdx.x;
+    const TraceWs &w = a.w;
+    if (m >= w.cnt[C_NSAMP]) return;
+    const int64_t i = w.list_samp[m];
+    const float *v = w.vals + m * (a.head + 1);
+    bool neg = false;
+    for (int s = 0; s < a.head; ++s) neg = neg || (v[s] < 0.0f);
+    const bool resolved = neg && a.obj[i] != 0;
+    w.tail_slot[m] = resolved ? -1 : atomicAdd(w.cnt + C_NSAMP2, 1);
+}
+
+__global__ __launch_bounds__(kTB) void sampler_tail_points_kernel(TraceArgs a) {
+    const int64_t gid = (int64_t)blockIdx.x * kTB + threadIdx.x;
+    const TraceWs &w = a.w;
+    const int per = a.n_steps - a.head - 1;
+    if (gid == 0) {
+        w.cnt[C_TAIL_PTS] = w.cnt[C_NSAMP2] * per;
+        w.cnt[C_NSAMP_PTS] = w.cnt[C_HEAD_PTS] + w.cnt[C_NSAMP2] * per;     // statistics: sampler evaluations
+    }
+    const int64_t m = gid / per;
+    if (m >= w.cnt[C_NSAMP]) return;
+    const int32_t q = w.tail_slot[m];
+    if (q < 0) return;
+    const int j = (int)(gid - m * per);
+    const int64_t i = w.list_samp[m];
+    const float lo = w.t_s[i], hi = w.t_e[i];
+    const float t = __fadd_rn(lo, __fmul_rn(a.fracs[a.head + j], __fsub_rn(hi, lo)));
+    float px, py, pz;
+    along(a, i, t, px, py, pz);
+    const int64_t o = a.tail_off + (int64_t)q * per + j;
+    w.pts[o * 3] = px; w.pts[o * 3 + 1] = py; w.pts[o * 3 + 2] = pz;
+}
+
 // first sign change / minimal sample per sampler ray, secant bracket set-up (ray_tracing.py:212-247)
 __global__ __launch_bounds__(kTB) void sampler_reduce_kernel(TraceArgs a) {
     const int64_t m = (int64_t)blockIdx.x * kTB + threadIdx.x;
@@ -234,21 +283,33 @@ __global__ __launch_bounds__(kTB) void sampler_reduce_kernel(TraceArgs a) {
     if (m >= w.cnt[C_NSAMP]) return;
     const int64_t i = w.list_samp[m];
     const int n = a.n_steps;
-    const float *v = w.vals + m * n;
+    // value of sample s: one [n_steps] row (single pass) or head row + second-pass row (lazy sampler)
+    const bool lazy = a.head > 0;
+    const int32_t tq = lazy ? w.tail_slot[m] : 0;    // second-pass slot, -1 = resolved by the head samples
+    const float *v_head = lazy ? w.vals + m * (a.head + 1) : w.vals + m * n;
+    const float *v_tail = lazy ? w.vals + a.tail_off + (int64_t)(tq < 0 ? 0 : tq) * (n - a.head - 1) - a.head : v_head;
+    const int head = a.head;
+    auto v = [&](int s) -> float {
+        if (!lazy) return v_head[s];
+        if (s < head) return v_head[s];
+        return s == n - 1 ? v_head[head] : v_tail[s];
+    };
+    // a ray resolved by its head samples has its first negative sample there: later samples cannot change `first`
+    // (their sign * rank is larger) and nothing else is read from them
+    const int n_scan = (lazy && tq < 0) ? head : n;
     int first = 0, amin = 0, bad = 0;
     float best_tmp = 0.0f, best_v = 0.0f;
-    for (int s = 0; s < n; ++s) {
-        const float x = v[s];
+    for (int s = 0; s < n_scan; ++s) {
+        const float x = v(s);
         bad += !isfinite(x);
         const float sg = (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f);
         const float tmp = sg * (float)(n - s);  // sign(sdf) * arange(n, 0, -1)
         if (s == 0 || tmp < best_tmp) { best_tmp = tmp; first = s; }
         if (s == 0 || x < best_v) { best_v = x; amin = s; }
     }
-    if (bad) atomicAdd(w.cnt + C_NONFINITE, bad);
     const float lo = w.t_s[i], hi = w.t_e[i];
     auto t_at = [&](int s) { return __fadd_rn(lo, __fmul_rn(a.fracs[s], __fsub_rn(hi, lo))); };
-    const float v_first = v[first];
+    const float v_first = v(first);
     const bool net_hit = v_first < 0.0f;
     const bool true_obj = a.obj[i] != 0;
     const int pick = (true_obj && net_hit) ? first : amin;
@@ -259,7 +320,8 @@ __global__ __launch_bounds__(kTB) void sampler_reduce_kernel(TraceArgs a) {
     const bool sec = a.training ? (net_hit && true_obj) : net_hit;
     if (sec) {
         const int lo_idx = first > 0 ? first - 1 : n - 1;  // index -1 wraps to the last sample, as in the reference
-        const float z_hi = t_at(first), v_hi = v_first, z_lo = t_at(lo_idx), v_lo = v[lo_idx];
+        const float z_hi = t_at(first), v_hi = v_first, z_lo = t_at(lo_idx), v_lo = v(lo_idx);
+        if (lazy && tq < 0 && lo_idx == n - 1 && !isfinite(v_lo)) ++bad;   // (outside the scanned range)
         const float z = secant_z(v_lo, v_hi, z_lo, z_hi);
         const int32_t q = atomicAdd(w.cnt + C_NSEC, 1);
         w.list_sec[q] = (int32_t)i;
@@ -269,6 +331,7 @@ __global__ __launch_bounds__(kTB) void sampler_reduce_kernel(TraceArgs a) {
             along(a, i, z, px, py, pz);
         }
     }
+    if (bad) atomicAdd(w.cnt + C_NONFINITE, bad);
     a.out_t[i] = t_out;
     w.t_s[i] = t_out;
     a.out_pts[i * 3] = px; a.out_pts[i * 3 + 1] = py; a.out_pts[i * 3 + 2] = pz;
@@ -341,7 +404,7 @@ __global__ __launch_bounds__(kTB) void closest_reduce_kernel(TraceArgs a) {
     if (m >= w.cnt[C_NSEL]) return;
     const int64_t i = w.list_sel[m];
     const int n = a.n_steps;
-    const float *v = w.vals + (int64_t)w.cnt[C_NSAMP_PTS] + m * n;   // behind the sampler's values (one launch)
+    const float *v = w.vals + (int64_t)w.cnt[a.head > 0 ? C_HEAD_PTS : C_NSAMP_PTS] + m * n;   // behind the sampler's first pass
     int amin = 0, bad = !isfinite(v[0]);
     float best = v[0];
     for (int s = 1; s < n; ++s) {
@@ -371,7 +434,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Layout {
     size_t off_f, off_i, off_b, off_pts, off_vals, off_cnt, off_emb, total;
-    int64_t cap;
+    int64_t cap;   // points of one SDF launch; pts / vals hold two such regions (the lazy sampler's second pass)
 };
 
 Layout make_layout(int64_t n, int n_steps, int emb_width = 0) {
@@ -379,10 +442,10 @@ Layout make_layout(int64_t n, int n_steps, int emb_width = 0) {
     L.cap = n * (n_steps > 2 ? n_steps : 2);
     size_t o = 0;
     L.off_f = o; o = align_up(o + sizeof(float) * 13 * (size_t)n, 256);
-    L.off_i = o; o = align_up(o + sizeof(int32_t) * 5 * (size_t)n, 256);
+    L.off_i = o; o = align_up(o + sizeof(int32_t) * 6 * (size_t)n, 256);
     L.off_b = o; o = align_up(o + 6 * (size_t)n, 256);
-    L.off_pts = o; o = align_up(o + sizeof(float) * 3 * (size_t)L.cap, 256);
-    L.off_vals = o; o = align_up(o + sizeof(float) * (size_t)L.cap, 256);
+    L.off_pts = o; o = align_up(o + sizeof(float) * 3 * 2 * (size_t)L.cap, 256);
+    L.off_vals = o; o = align_up(o + sizeof(float) * 2 * (size_t)L.cap, 256);
     L.off_cnt = o; o = align_up(o + sizeof(int32_t) * C_COUNT, 256);
     L.off_emb = o; o = align_up(o + sizeof(float) * (size_t)emb_width * (size_t)L.cap, 256);   // (filter-bank embedders)
     L.total = o;
@@ -469,6 +532,7 @@ static int trace_forward_impl(const hm_grid_desc *desc, const hm_nffb_desc *nffb
     a.w.v_lo = f + 10 * n; a.w.v_hi = f + 11 * n; a.w.z = f + 12 * n;
     int32_t *ip = reinterpret_cast<int32_t *>(base + L.off_i);
     a.w.slot_s = ip; a.w.slot_e = ip + n; a.w.list_samp = ip + 2 * n; a.w.list_sec = ip + 3 * n; a.w.list_sel = ip + 4 * n;
+    a.w.tail_slot = ip + 5 * n;
     uint8_t *bp = reinterpret_cast<uint8_t *>(base + L.off_b);
     a.w.live_s = bp; a.w.live_e = bp + n; a.w.stage = bp + 2 * n; a.w.it = bp + 3 * n; a.w.k = bp + 4 * n;
     a.w.is_samp = bp + 5 * n;
@@ -484,6 +548,9 @@ static int trace_forward_impl(const hm_grid_desc *desc, const hm_nffb_desc *nffb
     for (int k = 0; k < 4; ++k) a.back[k] = (float)((1.0 - cfg->line_search_step) / (double)(1 << k));
     a.ls_iters = cfg->line_step_iters; a.max_it = cfg->sphere_tracing_iters; a.n_steps = cfg->n_steps;
     a.n_secant = cfg->n_secant_steps; a.training = cfg->training;
+    // lazy sampler: a first pass over samples 0..head-1 and n_steps-1 only pays when it leaves something out
+    a.head = (cfg->sampler_head >= 1 && cfg->sampler_head + 1 < cfg->n_steps) ? cfg->sampler_head : 0;
+    a.tail_off = L.cap;
 
     hm_zero_u32_async(a.w.cnt, C_COUNT, st);
     const unsigned g_rays = (unsigned)((n_rays + kTB - 1) / kTB);
@@ -500,6 +567,32 @@ static int trace_forward_impl(const hm_grid_desc *desc, const hm_nffb_desc *nffb
         }
         return hm_sdf_fwd(desc, mlp, a.w.pts, capacity, table, B_fourier, a.w.vals, 1, 1, frac_mode, tile_points, n_dev,
                           0, stream);
+    };
+    // the coarse scans (sampler passes, closest approach): `off` = first point of the region in pts / vals
+    auto coarse = [&](int64_t off, int64_t capacity, const int32_t *n_dev) -> int {
+        const float *p = a.w.pts + off * 3;
+        float *v = a.w.vals + off;
+        int rc;
+        if (!cfg->coarse_bf16) {
+            if (nffb) {
+                rc = hm_nffb_fwd(desc, nffb, p, capacity, table, B_fourier, emb_ws, emb_width, frac_mode, n_dev, stream);
+                if (rc == HM_OK)
+                    rc = hm_sdf_fwd_emb(mlp, emb_ws, emb_width, emb_width, capacity, v, 1, 1, tile_points, n_dev, 0, stream);
+            } else {
+                rc = hm_sdf_fwd(desc, mlp, p, capacity, table, B_fourier, v, 1, 1, frac_mode, tile_points, n_dev, 0, stream);
+            }
+        } else if (nffb) {   // coarse scans in bf16 above 8192 live points, exact fp32 small tiles below
+            rc = hm_nffb_fwd(desc, nffb, p, capacity, table, B_fourier, emb_ws, emb_width, frac_mode, n_dev, stream);
+            if (rc == HM_OK)
+                rc = hm_sdf_fwd_emb(mlp, emb_ws, emb_width, emb_width, capacity, v, 1, 1, -1, n_dev, 0, stream);
+            if (rc == HM_OK)
+                rc = hm_sdf_fwd_emb_bf16(mlp, emb_ws, emb_width, emb_width, capacity, v, 1, n_dev, 8193, stream);
+        } else {
+            rc = hm_sdf_fwd(desc, mlp, p, capacity, table, B_fourier, v, 1, 1, frac_mode, -1, n_dev, 0, stream);
+            if (rc == HM_OK)
+                rc = hm_sdf_fwd_bf16(desc, mlp, p, capacity, table, B_fourier, v, 1, frac_mode, n_dev, 8193, stream);
+        }
+        return rc;
     };
 
     // ---- 1. bidirectional sphere tracing: one state-machine round per SDF launch -------------------
@@ -518,32 +611,25 @@ static int trace_forward_impl(const hm_grid_desc *desc, const hm_nffb_desc *nffb
     // n_steps random-fraction samples do not depend on the sampler's outcome: they are appended behind the
     // sampler's points and evaluated by the same launch (one dependent launch and one partial last wave less).
     if (cfg->training) hipLaunchKernelGGL(tail_prepare_kernel, dim3(g_rays), dim3(kTB), 0, st, a);
-    hipLaunchKernelGGL(ray_samples_kernel, dim3(g_samp), dim3(kTB), 0, st, a, a.w.list_samp, (int)C_NSAMP,
-                       (int)C_NSAMP_PTS, a.w.t_s, a.w.t_e, sampler_fracs, -1);
+    const int per_ray = a.head > 0 ? a.head + 1 : cfg->n_steps;    // samples per ray in the sampler's first pass
+    // (single pass: the first pass IS the sampler's evaluation count; lazy: the second pass adds to it later)
+    const int c_first = a.head > 0 ? (int)C_HEAD_PTS : (int)C_NSAMP_PTS;
+    hipLaunchKernelGGL(ray_samples_kernel, dim3((unsigned)((n_rays * per_ray + kTB - 1) / kTB)), dim3(kTB), 0, st, a,
+                       a.w.list_samp, (int)C_NSAMP, c_first, a.w.t_s, a.w.t_e, sampler_fracs, -1, per_ray);
     if (cfg->training)
         hipLaunchKernelGGL(ray_samples_kernel, dim3(g_samp), dim3(kTB), 0, st, a, a.w.list_sel, (int)C_NSEL,
-                           (int)C_NSEL_PTS, a.w.t_min, a.w.t_max, steps_u, (int)C_NSAMP_PTS);
+                           (int)C_NSEL_PTS, a.w.t_min, a.w.t_max, steps_u, c_first, cfg->n_steps);
     {
-        const int64_t capacity = n_rays * cfg->n_steps;
-        const int32_t *n_big = a.w.cnt + C_BIG_PTS;
-        int rc;
-        if (!cfg->coarse_bf16) {
-            rc = sdf(capacity, n_big);
-        } else if (nffb) {   // coarse scans in bf16 above 8192 live points, exact fp32 small tiles below
-            rc = hm_nffb_fwd(desc, nffb, a.w.pts, capacity, table, B_fourier, emb_ws, emb_width, frac_mode, n_big, stream);
-            if (rc == HM_OK)
-                rc = hm_sdf_fwd_emb(mlp, emb_ws, emb_width, emb_width, capacity, a.w.vals, 1, 1, -1, n_big, 0, stream);
-            if (rc == HM_OK)
-                rc = hm_sdf_fwd_emb_bf16(mlp, emb_ws, emb_width, emb_width, capacity, a.w.vals, 1, n_big, 8193, stream);
-        } else {
-            rc = hm_sdf_fwd(desc, mlp, a.w.pts, capacity, table, B_fourier, a.w.vals, 1, 1, frac_mode, -1, n_big, 0, stream);
-            if (rc == HM_OK)
-                rc = hm_sdf_fwd_bf16(desc, mlp, a.w.pts, capacity, table, B_fourier, a.w.vals, 1, frac_mode, n_big, 8193,
-                                     stream);
-        }
+        int rc = coarse(0, n_rays * cfg->n_steps, a.w.cnt + C_BIG_PTS);
         if (rc != HM_OK) return rc;
     }
     if (cfg->training) hipLaunchKernelGGL(closest_reduce_kernel, dim3(g_rays), dim3(kTB), 0, st, a);
+    if (a.head > 0) {   // second pass: the remaining samples of the rays the head samples did not resolve
+        hipLaunchKernelGGL(sampler_head_kernel, dim3(g_rays), dim3(kTB), 0, st, a);
+        hipLaunchKernelGGL(sampler_tail_points_kernel, dim3(g_samp), dim3(kTB), 0, st, a);
+        int rc = coarse(a.tail_off, n_rays * (cfg->n_steps - a.head - 1), a.w.cnt + C_TAIL_PTS);
+        if (rc != HM_OK) return rc;
+    }
     hipLaunchKernelGGL(sampler_reduce_kernel, dim3(g_rays), dim3(kTB), 0, st, a);
     if (cfg->n_secant_steps > 0) {
         hipLaunchKernelGGL(secant_points_kernel, dim3(g_rays), dim3(kTB), 0, st, a);

@@ -36,6 +36,11 @@ class RayTracing(nn.Module):
         self.verbose = False      # the reference prints three lines per call (:61-64), each a device sync
         self.steps_override = None  # optional [n_steps] tensor replacing the U(0,1) draw of step 3
         self.use_device_tracer = True   # sync-free HIP state-machine tracer when `sdf` is the package's network
+        # device tracer: the sampler's first pass evaluates samples 0..sampler_head-1 (and the last one), the second
+        # pass the remaining samples of the rays whose first sign change is not among them - the reference reads
+        # nothing past a ray's first negative sample (:212-218), so the outputs are bit-identical to evaluating all
+        # n_steps samples of every ray (sampler_head = 0, what the reference and the generic path below do)
+        self.sampler_head = 16
         self._stats = {}
         self._stats_dev = None
         self._ws = None
@@ -47,7 +52,8 @@ class RayTracing(nn.Module):
             v = self._stats_dev.tolist()
             # (the device tensor is kept: inside a captured graph it is refreshed by every replay)
             self._stats = {"rays": self._stats.get("rays"), "sampler_rays": v[0], "secant_rays": v[2],
-                           "mask_loss_rays": v[3], "sdf_evals": v[6], "unfinished": v[7], "nonfinite": v[8]}
+                           "mask_loss_rays": v[3], "sdf_evals": v[6], "unfinished": v[7], "nonfinite": v[8],
+                           "sampler_points": v[1], "sampler_second_pass_rays": v[10]}
         return self._stats
 
     def _fused_network(self, sdf, ray_directions):
@@ -68,7 +74,8 @@ class RayTracing(nn.Module):
             cfg = _lib.TraceCfg(float(self.object_bounding_sphere), float(self.sdf_threshold),
                                 float(self.line_search_step), int(self.line_step_iters),
                                 int(self.sphere_tracing_iters), int(self.n_steps), int(self.n_secant_steps),
-                                1 if self.training else 0, 1 if getattr(net, "bf16_coarse_search", False) else 0)
+                                1 if self.training else 0, 1 if getattr(net, "bf16_coarse_search", False) else 0,
+                                int(self.sampler_head))
             nf = net._nffb_embedder() if net._hash_embedder() is None else None
             need = ops.trace_workspace_bytes(N, cfg, nf.n_levels if nf is not None else 0)
             if self._ws is None or self._ws.numel() < need or self._ws.device != dev:

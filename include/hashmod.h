@@ -270,7 +270,8 @@ HM_API int hm_nffb_fwd(const hm_grid_desc *desc, const hm_nffb_desc *nf, const f
  * outputs: points [N,3], network_object_mask [N] bytes, dists [N];
  * stats_out (optional, 16 device int32): sampler rays, sampler points, secant rays, mask-loss rays,
  *   their points, any-iteration flag, total SDF evaluations, unfinished rays (must be 0), non-finite SDF
- *   values met by the search (must be 0), 7 reserved.                                              */
+ *   values met by the search (must be 0), points of the big launch, lazy sampler: rays of the second pass, points of
+ *   the first pass, points of the second pass, 3 reserved.                                          */
 typedef struct hm_trace_cfg {
     float object_bounding_sphere;
     float sdf_threshold;
@@ -282,6 +283,13 @@ typedef struct hm_trace_cfg {
     int32_t training;
     int32_t coarse_bf16;           /* != 0: the sampler / closest-approach scans run on hm_sdf_fwd_bf16 (needs w_packed_bf16);
                                       sphere tracing and the secant refinement stay on the exact-fp32 kernels */
+    int32_t sampler_head;          /* lazy sampler.  ray_sampler (ray_tracing.py:189-249) evaluates n_steps samples per
+                                      unconverged ray but reads only those up to the FIRST negative one (:212-218, and
+                                      its predecessor for the secant bracket, :238-243) unless the ray falls back to the
+                                      minimal sample (:221-226).  h = sampler_head in [1, n_steps-2]: a first pass
+                                      evaluates samples 0..h-1 and n_steps-1; rays with a negative head sample inside
+                                      the object mask are finished, the others get samples h..n_steps-2 in a second
+                                      pass.  Outputs are bit-identical to the single pass (0 / out of range).       */
 } hm_trace_cfg;
 
 HM_API int64_t hm_trace_workspace_bytes(int64_t n_rays, const hm_trace_cfg *cfg);

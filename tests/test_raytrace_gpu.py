@@ -163,3 +163,49 @@ def test_device_tracer_edge_cases(golden, case, mode):
     assert torch.equal(d1, d2) and torch.equal(p1, p2)
     if case == "all_miss_sphere":
         assert not bool(m1.any())
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+@pytest.mark.parametrize("tag,n_rays", [("bumpy", 2048), ("bumpy", 77), ("C2", None)])
+def test_lazy_sampler_equals_single_pass(golden, tag, n_rays, mode):
+    """hm_trace_cfg.sampler_head: evaluating a sampler ray's samples only up to its first sign change (two passes)
+    gives the same points / mask / distances, bit for bit, as evaluating all n_steps samples of every unconverged ray
+    like the reference does (ray_tracing.py:189-249) - and fewer SDF evaluations.  Fixed 64-point tiles, so that an SDF
+    value does not depend on which launch computed it."""
+    from hashmodnffbanks_idr_amd.model.ray_tracing import RayTracing
+    import params as P
+    g = golden(f"raytrace_{tag}")
+    net = _net(g, tag)
+    net.eval()
+    net.sdf_tile_points = 64
+    if n_rays is None:
+        cam, dirs, om = g["cam_loc"], g["ray_dirs"], g["object_mask"]
+    else:
+        cam, dirs = P.make_rays(3, n_rays)
+        om = np.random.RandomState(3).uniform(0, 1, n_rays) < 0.7
+    res = {}
+    for head in (0, 1, 5, 16, 50, 98, 99, 1000):
+        rt = RayTracing(1.0, 5.0e-5, 0.5, 3, 10, 100, 8).cuda()
+        rt.train(mode == "train")
+        rt.sampler_head = head
+        rt.steps_override = torch.from_numpy(g["steps"])
+        with torch.no_grad():
+            out = rt(sdf=net.sdf, cam_loc=torch.from_numpy(cam).cuda(), object_mask=torch.from_numpy(om).cuda(),
+                     ray_directions=torch.from_numpy(dirs).cuda())
+        st = rt.last_stats
+        assert st["unfinished"] == 0 and st["nonfinite"] == 0
+        res[head] = (out, st)
+    (p0, m0, d0), st0 = res[0]
+    assert st0["sampler_points"] == 100 * st0["sampler_rays"]
+    for head, ((p, m, d), st) in res.items():
+        assert torch.equal(m, m0) and torch.equal(d, d0) and torch.equal(p, p0), head
+        assert st["sampler_rays"] == st0["sampler_rays"] and st["secant_rays"] == st0["secant_rays"]
+        if 1 <= head <= 98:
+            assert st["sampler_points"] == (head + 1) * st["sampler_rays"] + (99 - head) * st["sampler_second_pass_rays"]
+            assert st["sdf_evals"] <= st0["sdf_evals"]
+        else:       # out of range: single pass
+            assert st["sdf_evals"] == st0["sdf_evals"]
+    print(f"lazy sampler {tag}/{mode}: sampler rays {st0['sampler_rays']}, SDF evaluations "
+          + ", ".join(f"head {h}: {r[1]['sdf_evals']}" for h, r in res.items()))
+    if tag == "C2":      # near the geometric initialisation the first sign change comes early
+        assert res[16][1]["sdf_evals"] < 0.9 * st0["sdf_evals"]
