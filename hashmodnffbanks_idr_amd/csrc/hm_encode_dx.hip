@@ -147,6 +147,76 @@ __global__ __launch_bounds__(kThreads) void encode_bwd_input_kernel(HmLevels lv,
     }
 }
 
+// ---- Fourier-feature columns of the embedding row [x | sin(a) | cos(a) | hash features], a_c = 2 pi x . B[:, c] -------
+// (frequency_enc.py:63-67; same fp32 expression as the forward kernel: s = 2 pi x, k-ordered fma chain)
+__device__ __forceinline__ float fourier_arg(const float *__restrict__ Bf, int L, int c, float s0, float s1, float s2) {
+    float a = __fmul_rn(s0, Bf[c]);
+    a = __fmaf_rn(s1, Bf[L + c], a);
+    return __fmaf_rn(s2, Bf[2 * L + c], a);
+}
+
+// gx = d_row[:, 0:3] + 2 pi sum_c B[:, c] (cos_c d_sin_c - sin_c d_cos_c): backward of the row w.r.t. x (the hash
+// features of the reference's frac mode do not depend on x)
+__global__ __launch_bounds__(kThreads) void fourier_bwd_input_kernel(const float *__restrict__ x, int64_t n,
+                                                                     const float *__restrict__ Bf, int L,
+                                                                     const float *__restrict__ d_row, int64_t ld,
+                                                                     float *__restrict__ gx) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const float two_pi = 6.283185307179586f;
+    const float s0 = __fmul_rn(two_pi, x[i * 3]), s1 = __fmul_rn(two_pi, x[i * 3 + 1]), s2 = __fmul_rn(two_pi, x[i * 3 + 2]);
+    const float *d = d_row + i * ld;
+    float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f;
+    for (int c = 0; c < L; ++c) {
+        float sn, cs;
+        sincosf(fourier_arg(Bf, L, c, s0, s1, s2), &sn, &cs);
+        const float q = cs * d[3 + c] - sn * d[3 + L + c];
+        g0 += q * Bf[c]; g1 += q * Bf[L + c]; g2 += q * Bf[2 * L + c];
+    }
+    gx[i * 3] = d[0] + two_pi * g0;
+    gx[i * 3 + 1] = d[1] + two_pi * g1;
+    gx[i * 3 + 2] = d[2] + two_pi * g2;
+}
+
+// backward of gx(x, d_row) along gg [n,3]:  with p_c = B[:, c] . gg
+//   dd_row = [gg | 2 pi p_c cos_c | -2 pi p_c sin_c | 0 ...],   d_x = -(2 pi)^2 sum_c B[:, c] p_c (sin_c d_sin_c + cos_c d_cos_c)
+__global__ __launch_bounds__(kThreads) void fourier_bwd_input_bwd_kernel(const float *__restrict__ x, int64_t n,
+                                                                         const float *__restrict__ Bf, int L,
+                                                                         const float *__restrict__ d_row, int64_t ld,
+                                                                         const float *__restrict__ gg,
+                                                                         float *__restrict__ d_x,
+                                                                         float *__restrict__ dd_row, int64_t ld2,
+                                                                         int width) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const float two_pi = 6.283185307179586f;
+    const float s0 = __fmul_rn(two_pi, x[i * 3]), s1 = __fmul_rn(two_pi, x[i * 3 + 1]), s2 = __fmul_rn(two_pi, x[i * 3 + 2]);
+    const float *d = d_row + i * ld;
+    const float q0 = gg[i * 3], q1 = gg[i * 3 + 1], q2 = gg[i * 3 + 2];
+    float *o = dd_row ? dd_row + i * ld2 : nullptr;
+    if (o) {
+        o[0] = q0; o[1] = q1; o[2] = q2;
+        for (int k = 3 + 2 * L; k < width; ++k) o[k] = 0.0f;
+    }
+    float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f;
+    for (int c = 0; c < L; ++c) {
+        float sn, cs;
+        sincosf(fourier_arg(Bf, L, c, s0, s1, s2), &sn, &cs);
+        const float b0 = Bf[c], b1 = Bf[L + c], b2 = Bf[2 * L + c];
+        const float pc = b0 * q0 + b1 * q1 + b2 * q2;
+        if (o) {
+            o[3 + c] = two_pi * pc * cs;
+            o[3 + L + c] = -(two_pi * pc * sn);
+        }
+        const float r = pc * (sn * d[3 + c] + cs * d[3 + L + c]);
+        g0 += r * b0; g1 += r * b1; g2 += r * b2;
+    }
+    if (d_x) {
+        const float k2 = -(two_pi * two_pi);
+        d_x[i * 3] = k2 * g0; d_x[i * 3 + 1] = k2 * g1; d_x[i * 3 + 2] = k2 * g2;
+    }
+}
+
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 bool grid_ok(int64_t threads, int64_t &grid) {
@@ -204,6 +274,36 @@ int hm_encode_bwd_table_jvp(const hm_grid_desc *desc, const float *x, int64_t n,
     hipLaunchKernelGGL(encode_bwd_table_jvp_kernel, dim3((unsigned)grid), dim3(kThreads), 0, as_stream(stream),
                        desc->lv, x, n, a, d_feat, d_feat_stride, d_table);
     HM_CHECK_LAUNCH("hm_encode_bwd_table_jvp");
+    return HM_OK;
+}
+
+int hm_fourier_bwd_input(const float *x, int64_t n, const float *B_fourier, int n_channels, const float *d_row,
+                         int64_t d_row_stride, float *gx, void *stream) {
+    HM_CHECK_ARG(n >= 0 && n_channels >= 1 && n_channels <= HM_MAX_LEVELS, "hm_fourier_bwd_input: bad size");
+    HM_CHECK_ARG(d_row_stride >= 3 + 2 * n_channels, "hm_fourier_bwd_input: d_row_stride < 3 + 2 n_channels");
+    if (n == 0) return HM_OK;
+    HM_CHECK_ARG(x && B_fourier && d_row && gx, "hm_fourier_bwd_input: NULL pointer");
+    int64_t grid;
+    HM_CHECK_ARG(grid_ok(n, grid), "hm_fourier_bwd_input: n too large for one launch");
+    hipLaunchKernelGGL(fourier_bwd_input_kernel, dim3((unsigned)grid), dim3(kThreads), 0, as_stream(stream), x, n,
+                       B_fourier, n_channels, d_row, d_row_stride, gx);
+    HM_CHECK_LAUNCH("hm_fourier_bwd_input");
+    return HM_OK;
+}
+
+int hm_fourier_bwd_input_bwd(const float *x, int64_t n, const float *B_fourier, int n_channels, const float *d_row,
+                             int64_t d_row_stride, const float *gg, float *d_x, float *dd_row, int64_t dd_row_stride,
+                             int width, void *stream) {
+    HM_CHECK_ARG(n >= 0 && n_channels >= 1 && n_channels <= HM_MAX_LEVELS, "hm_fourier_bwd_input_bwd: bad size");
+    HM_CHECK_ARG(d_row_stride >= 3 + 2 * n_channels, "hm_fourier_bwd_input_bwd: d_row_stride < 3 + 2 n_channels");
+    HM_CHECK_ARG(!dd_row || (width >= 3 + 2 * n_channels && dd_row_stride >= width), "hm_fourier_bwd_input_bwd: dd_row shape");
+    if (n == 0) return HM_OK;
+    HM_CHECK_ARG(x && B_fourier && d_row && gg && (d_x || dd_row), "hm_fourier_bwd_input_bwd: NULL pointer");
+    int64_t grid;
+    HM_CHECK_ARG(grid_ok(n, grid), "hm_fourier_bwd_input_bwd: n too large for one launch");
+    hipLaunchKernelGGL(fourier_bwd_input_bwd_kernel, dim3((unsigned)grid), dim3(kThreads), 0, as_stream(stream), x, n,
+                       B_fourier, n_channels, d_row, d_row_stride, gg, d_x, dd_row, dd_row_stride, width);
+    HM_CHECK_LAUNCH("hm_fourier_bwd_input_bwd");
     return HM_OK;
 }
 

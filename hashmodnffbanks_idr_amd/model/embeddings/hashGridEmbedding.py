@@ -73,6 +73,7 @@ class MultiResHashGridMLP(nn.Module):
         self.freq_encoding = self.freq_encoding.to(DEVICE)
         self.embeddings_dim = in_dim + n_levels * max_points_per_level + (self.freq_encoding.embeddings_dim - in_dim)
         self.grad_collector = None   # parallel.PointGradExchange when the table gradient is exchanged sparsely
+        self.fused_input_grad = True  # False: d/dx of the Fourier columns through torch's elementwise autograd
         self._register_state_dict_hook(MultiResHashGridMLP._split_table_hook)
         self._register_load_state_dict_pre_hook(self._fuse_table_hook)
 
@@ -114,12 +115,16 @@ class MultiResHashGridMLP(nn.Module):
         elif not x2.requires_grad:
             # only the table needs a gradient: one fused kernel, backward = table scatter
             out = ops.encode_table_grad(x2, self.table, B, self.desc, fm, self.grad_collector)
+        elif self.frac_mode == "reference" and x2.is_cuda and self.fused_input_grad:
+            # the points need a gradient too (ImplicitNetwork.gradient, create_graph=True): still ONE encoder launch;
+            # the row's dependence on x - the pass-through and Fourier columns, the reference's hash features have
+            # none (hashGridEmbedding.py:86) - is a second autograd node with hand-written first / second order
+            # kernels.  The table node stays OFF the x-graph: autograd.grad(e, x, create_graph=True) would otherwise
+            # run its backward (a dense scatter that is then thrown away - a custom Function cannot see that only
+            # d/dx was asked for), and a sparse gradient collector would record a bogus contribution
+            out = ops.embed_row_input_grad(x2, self.table, B, self.desc, self.grad_collector)
         else:
             four = self.freq_encoding(x2.float())
-            # reference frac mode: d(hash features)/dx is identically 0 (hashGridEmbedding.py:86), so the node is kept
-            # OFF the x-graph: autograd.grad(e, x, create_graph=True) in ImplicitNetwork.gradient would otherwise run
-            # this node's table backward (a dense scatter that is then thrown away - a custom Function cannot see
-            # that only d/dx was asked for), and a sparse gradient collector would record a bogus contribution
             xh = x2.detach() if self.frac_mode == "reference" else x2
             feat = ops.hash_features(xh, self.table, self.desc, fm, self.grad_collector)
             out = torch.cat([four, feat], dim=-1)

@@ -229,6 +229,63 @@ class _HashScatter(torch.autograd.Function):
         return None, gg, None, None
 
 
+class _AttachInputGrad(torch.autograd.Function):
+    """Puts the full embedding row [x | sin | cos | hash features] (already computed by ONE encoder launch as a
+    table-gradient-only node, encode_table_grad) onto the graph of the points x: the row is returned as it is
+    (mark_dirty, no copy); backward hands d_row on to the table node and produces d_x = _RowInputGrad.  Two nodes, so
+    that autograd.grad(e, x, create_graph=True) (ImplicitNetwork.gradient) does not run the table backward at all:
+    the engine only visits producers of the inputs that were asked for.  Reference frac mode only (the hash features
+    do not depend on x there, hashGridEmbedding.py:86)."""
+
+    @staticmethod
+    def forward(ctx, row, x, B):
+        ctx.save_for_backward(x, B)
+        ctx.mark_dirty(row)
+        return row
+
+    @staticmethod
+    def backward(ctx, d_row):
+        x, B = ctx.saved_tensors
+        d_x = _RowInputGrad.apply(x, B, d_row) if ctx.needs_input_grad[1] else None
+        return (d_row if ctx.needs_input_grad[0] else None), d_x, None
+
+
+class _RowInputGrad(torch.autograd.Function):
+    """gx = d_row[:, :3] + (d Fourier columns / d x)^T d_row as ONE kernel, differentiable once more: the eikonal /
+    normal terms' backward arrives as gg and leaves towards d_row and x in one kernel too (csrc/hm_encode_dx.hip).
+    The torch expression of the same thing is ~10 elementwise kernels and a K = 3 vendor matmul per pass."""
+
+    @staticmethod
+    def forward(ctx, x, B, d_row):
+        d_row = _rowmajor(d_row)
+        ctx.save_for_backward(x, B, d_row)
+        gx = torch.empty_like(x)
+        check(lib().hm_fourier_bwd_input(dptr(x), x.shape[0], dptr(B), B.shape[1], dptr(d_row), _ld(d_row), dptr(gx),
+                                         stream_ptr(x)))
+        return gx
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gg):
+        x, B, d_row = ctx.saved_tensors
+        n, width = d_row.shape
+        gg = gg.contiguous()
+        d_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dd = torch.empty((n, width), dtype=torch.float32, device=x.device) if ctx.needs_input_grad[2] else None
+        if d_x is not None or dd is not None:
+            check(lib().hm_fourier_bwd_input_bwd(dptr(x), n, dptr(B), B.shape[1], dptr(d_row), _ld(d_row), dptr(gg),
+                                                 dptr(d_x), dptr(dd), width, width, stream_ptr(x)))
+        return d_x, None, dd
+
+
+def embed_row_input_grad(x, table, B, desc, collector=None):
+    """[N,E] embedding row in ONE kernel, differentiable w.r.t. the table (any order) and w.r.t. x (twice) -
+    reference frac mode."""
+    x = _prep_x(x)
+    row = _HashFeatures.apply(x.detach(), table, B, desc, 0, collector)
+    return _AttachInputGrad.apply(row, x, B)
+
+
 def hash_features(x, table, desc, frac_mode=0, collector=None):
     """[N,L*F] hash features with autograd (table grads of any order)."""
     return _HashFeatures.apply(_prep_x(x), table, None, desc, frac_mode, collector)

@@ -146,6 +146,21 @@ HM_API int hm_encode_jvp(const hm_grid_desc *desc, const float *x, int64_t n, co
 HM_API int hm_encode_bwd_table_jvp(const hm_grid_desc *desc, const float *x, int64_t n, const float *a,
                                    const float *d_feat, int64_t d_feat_stride, float *d_table, void *stream);
 
+/* ---- embedding row: input gradient of the Fourier-feature columns -------------------------------------------------
+ * MultiResHashGridMLP.forward returns [x | sin(a) | cos(a) | level features] with a = 2 pi x B (hashGridEmbedding.py:
+ * 150-155, frequency_enc.py:63-67).  In the reference autograd differentiates that expression w.r.t. x with
+ * create_graph=True (ImplicitNetwork.gradient, implicit_differentiable_renderer.py:116-127: ~10 elementwise kernels
+ * and a K=3 matmul per pass) and once more in loss.backward(); the hash features contribute nothing (:86).
+ *   hm_fourier_bwd_input      gx[i,:] = d_row[i,0:3] + 2 pi sum_c B[:,c] (cos_c d_sin_c - sin_c d_cos_c)
+ *   hm_fourier_bwd_input_bwd  given gg [n,3]:  dd_row = d(gg . gx)/d(d_row)  ([n,width], hash columns zero; may be NULL)
+ *                                              d_x    = d(gg . gx)/dx        ([n,3]; may be NULL)
+ * B_fourier [3, n_channels]; d_row rows [x(3) | sin(n_channels) | cos(n_channels) | ...] with the given stride.     */
+HM_API int hm_fourier_bwd_input(const float *x, int64_t n, const float *B_fourier, int n_channels, const float *d_row,
+                                int64_t d_row_stride, float *gx, void *stream);
+HM_API int hm_fourier_bwd_input_bwd(const float *x, int64_t n, const float *B_fourier, int n_channels,
+                                    const float *d_row, int64_t d_row_stride, const float *gg, float *d_x,
+                                    float *dd_row, int64_t dd_row_stride, int width, void *stream);
+
 /* ---- fused SDF network forward (no grad) ---------------------------------------------------
  * Replaces ImplicitNetwork.forward evaluated under torch.no_grad()
  * (model/implicit_differentiable_renderer.py:89-113 + density_net.py:20-30), i.e. the `sdf`

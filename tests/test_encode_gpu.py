@@ -290,3 +290,42 @@ def test_trilinear_mode_trains_with_eikonal_term():
         opt.step()
         losses.append(lo["loss"].item())
     assert all(np.isfinite(losses)), losses
+
+
+@pytest.mark.parametrize("cfg", ["C1", "C2"])
+def test_embedding_row_input_gradient_matches_torch_autograd(cfg):
+    """MultiResHashGridMLP with points that need a gradient: the fused route (one encoder launch + the hand-written
+    first / second order kernels of the Fourier columns, hm_fourier_bwd_input[_bwd]) against torch's autograd over the
+    FourierFeature expression (frequency_enc.py:63-67) - values, d/dx with create_graph, and the backward of a loss
+    on that gradient w.r.t. x, the upstream gradient and the table"""
+    import params as P
+    from hashmodnffbanks_idr_amd.model.embeddings.hashGridEmbedding import MultiResHashGridMLP
+    L, T, b, d = P.CONFIGS[cfg]
+    torch.manual_seed(0)
+    emb = MultiResHashGridMLP(True, 3, L, 2, T, b, d).cuda()
+    with torch.no_grad():
+        emb.table.uniform_(-0.5, 0.5)
+    n = 3000
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x0 = (torch.rand((n, 3), generator=g) * 2 - 1).cuda()
+    m0 = torch.randn((n, emb.embeddings_dim), generator=g).cuda()
+    r_vec = torch.randn((n, 3), generator=g).cuda()
+
+    def run(fused):
+        emb.fused_input_grad = fused
+        emb.table.grad = None
+        x = x0.clone().requires_grad_(True)
+        m = m0.clone().requires_grad_(True)
+        e = emb(x)
+        (gx,) = torch.autograd.grad((e * m).sum(), x, create_graph=True)
+        assert emb.table.grad is None                      # the create_graph pass must not touch the table
+        loss = (gx * r_vec).pow(2).sum() + 0.1 * e.pow(2).sum()
+        loss.backward()
+        return e.detach(), gx.detach(), x.grad, m.grad, emb.table.grad.clone()
+
+    got, ref = run(True), run(False)
+    for name, a, b_ in zip(("row", "d/dx", "loss d/dx", "loss d/dm", "loss d/dtable"), got, ref):
+        scale = b_.abs().max().item()
+        err = (a - b_).abs().max().item()
+        print(f"embedding row {cfg} {name}: max |d| {err:.3e} (scale {scale:.3e})")
+        assert scale > 0 and err <= 2e-5 * scale, name
