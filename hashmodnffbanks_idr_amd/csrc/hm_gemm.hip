@@ -14,6 +14,8 @@
 // tile so that one stage of MFMAs (~0.85 us) covers the L2 latency of the next stage's loads.
 #include "hm_common.h"
 
+#include <stdio.h>
+
 #include <stdlib.h>
 
 namespace {
@@ -552,6 +554,8 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K, co
     int64_t k_chunk = (K + split - 1) / split;
     k_chunk = ((k_chunk + kBK - 1) / kBK) * kBK;
     if (k_chunk == 0) k_chunk = kBK;
+    // the pipelined kernel has no K tail: grow the chunk until it divides K (K = 6144 over 10 splits: 640 -> 768)
+    while (use_pipe && K % k_chunk != 0 && k_chunk < K) k_chunk += kBK;
     split = K > 0 ? (K + k_chunk - 1) / k_chunk : 1;
     g.k_chunk = (int)k_chunk;
     const bool pipe_ok = use_pipe && K % k_chunk == 0;   // (the pipelined kernel has no K-tail handling)
@@ -610,8 +614,14 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K, co
         else if (b_kc) HM_PIPE_LAUNCH(false, true);
         else HM_PIPE_LAUNCH(false, false);
 #undef HM_PIPE_LAUNCH
-    } else
+    } else {
+        static const int log_cfg = [] { const char *e = getenv("HM_GEMM_LOG"); return e ? atoi(e) : 0; }();
+        if (log_cfg)   // debugging: which shapes miss the pipelined kernel
+            fprintf(stderr, "hm_gemm_f32 generic: tA %d tB %d M %lld N %lld K %lld lda %lld ldb %lld ep %d vecA %d vecB %d split %lld\n",
+                    transA, transB, (long long)M, (long long)N, (long long)K, (long long)lda, (long long)ldb, g.ep.mode,
+                    g.vecA, g.vecB, (long long)split);
         HM_GEMM_LAUNCH(1, 1, 128, 2, 2);
+    }
 #undef HM_GEMM_LAUNCH
     HM_CHECK_LAUNCH("hm_gemm_f32");
     return HM_OK;
