@@ -29,6 +29,11 @@ namespace {
 
 #include "hm_sdf_common.h"
 
+// third value of the kernels' FRAC template parameter: `x` holds PRECOMPUTED embedding rows (hm_sdf_fwd_emb).  A template
+// value rather than a run-time branch on net.emb_stride: with both input paths in one kernel body the register
+// allocation of the hash-grid variant changed (178 -> 205 VGPRs, 33 -> 42 spilled SGPRs) and it lost 4 %.
+constexpr int kFracEmb = 2;
+
 constexpr int kPts = 64;        // points per workgroup tile
 constexpr int kThreadsSdf = 512;
 constexpr int kWaves = 8;
@@ -63,11 +68,11 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_kernel(HmLevels lv, Sd
         const int64_t base = tile * kPts;
         const int cnt = (int)min((int64_t)kPts, n - base);
         __syncthreads();  // previous tile's output stage is done with X
-        if (net.emb_stride == 0 && tid < kPts * 3) SX[tid] = (tid < cnt * 3) ? x[base * 3 + tid] : 0.0f;
+        if (FRAC != kFracEmb && tid < kPts * 3) SX[tid] = (tid < cnt * 3) ? x[base * 3 + tid] : 0.0f;
         __syncthreads();
 
         // ---------------- encode -> EMB[(e/4)][p][e%4] ------------------------------------
-        if (net.emb_stride > 0) {
+        if constexpr (FRAC == kFracEmb) {
             load_emb_tile(EMB, x, net.emb_stride, base, cnt, E, net.emb_groups, kPts, kGroupFloats, tid, kThreadsSdf);
         } else {
             const int p = tid & (kPts - 1);
@@ -323,11 +328,11 @@ __global__ __launch_bounds__(kThreads32, 2) void sdf_fwd_p32_kernel(HmLevels lv,
         const int64_t base = tile * kPts32;
         const int cnt = (int)min((int64_t)kPts32, n - base);
         __syncthreads();
-        if (net.emb_stride == 0 && tid < kPts32 * 3) SX[tid] = (tid < cnt * 3) ? x[base * 3 + tid] : 0.0f;
+        if (FRAC != kFracEmb && tid < kPts32 * 3) SX[tid] = (tid < cnt * 3) ? x[base * 3 + tid] : 0.0f;
         __syncthreads();
 
         // ---------------- encode -> EMB[(e/4)][p][e%4]: thread -> (point p, slot grp of 8) ----------------
-        if (net.emb_stride > 0) {
+        if constexpr (FRAC == kFracEmb) {
             load_emb_tile(EMB, x, net.emb_stride, base, cnt, E, net.emb_groups, kPts32, kGroupFloats32, tid, kThreads32);
         } else {
             const int p = tid & (kPts32 - 1);
@@ -545,11 +550,11 @@ __device__ __forceinline__ void sdf_m16_body(const HmLevels &lv, const SdfNet &n
         const int64_t base = tile * kPts16;
         const int cnt = (int)min((int64_t)kPts16, n - base);
         __syncthreads();
-        if (net.emb_stride == 0 && tid < kPts16 * 3) SX[tid] = (tid < cnt * 3) ? x[base * 3 + tid] : 0.0f;
+        if (FRAC != kFracEmb && tid < kPts16 * 3) SX[tid] = (tid < cnt * 3) ? x[base * 3 + tid] : 0.0f;
         __syncthreads();
 
         // ---- encode: thread -> (point p, slot c); 32 slots cover channels / levels
-        if (net.emb_stride > 0) {
+        if constexpr (FRAC == kFracEmb) {
             load_emb_tile(EMB, x, net.emb_stride, base, cnt, E, emb_groups16, kPts16, kGroupFloats16, tid, kThreadsSdf);
         } else {
             const int p = tid & (kPts16 - 1);
@@ -790,11 +795,11 @@ __device__ __forceinline__ void sdf_m8_body(const HmLevels &lv, const SdfNet &ne
         const int64_t base = tile * PTS;
         const int cnt = (int)min((int64_t)PTS, n - base);
         __syncthreads();
-        if (net.emb_stride == 0 && tid < kPts8 * 3) SX[tid] = (tid < cnt * 3) ? x[base * 3 + tid] : 0.0f;
+        if (FRAC != kFracEmb && tid < kPts8 * 3) SX[tid] = (tid < cnt * 3) ? x[base * 3 + tid] : 0.0f;
         __syncthreads();
 
         // ---- encode: thread -> (point p, slot c0); 64 slots cover channels / levels
-        if (net.emb_stride > 0) {
+        if constexpr (FRAC == kFracEmb) {
             load_emb_tile(EMB, x, net.emb_stride, base, cnt, E, emb_groups16, PTS, kGroupFloats8, tid, kThreadsSdf);
         } else {
             const int p = tid & (kPts8 - 1);
@@ -1076,6 +1081,7 @@ static int sdf_fwd_impl(const HmLevels &lv, const hm_mlp_desc *mlp, const float 
     net.n_layers = mlp->n_layers;
     net.beta = mlp->beta;
     net.emb_stride = emb_stride;
+    const int mode = emb_stride > 0 ? kFracEmb : frac_mode;    // kernel template value
     const int emb_oct = (lv.E + 7) / 8;
     const int emb_b16 = (lv.E + 15) / 16;
     net.emb_groups = emb_oct * 2;
@@ -1145,6 +1151,9 @@ static int sdf_fwd_impl(const HmLevels &lv, const hm_mlp_desc *mlp, const float 
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(sdf_fwd_kernel<HM_FRAC_TRILINEAR>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(sdf_fwd_kernel<kFracEmb>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return hm_fail(HM_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
         attr_done = true;
     }
@@ -1164,7 +1173,11 @@ static int sdf_fwd_impl(const HmLevels &lv, const hm_mlp_desc *mlp, const float 
         }
         const int64_t cap = max_workgroups > 0 ? max_workgroups : 256;  // one resident workgroup per CU
         const int64_t grid = tiles < cap ? tiles : cap;
-        if (frac_mode == HM_FRAC_REFERENCE)
+        if (mode == kFracEmb)
+            hipLaunchKernelGGL(sdf_fwd_small_kernel<kFracEmb>, dim3((unsigned)grid), dim3(kThreadsSdf), lds,
+                               as_stream(stream), lv, net, x, n, table, B_fourier, out, out_stride, out_cols, n_dev,
+                               lo16, hi16, m8_max, m4_max);
+        else if (mode == HM_FRAC_REFERENCE)
             hipLaunchKernelGGL(sdf_fwd_small_kernel<HM_FRAC_REFERENCE>, dim3((unsigned)grid), dim3(kThreadsSdf), lds,
                                as_stream(stream), lv, net, x, n, table, B_fourier, out, out_stride, out_cols, n_dev,
                                lo16, hi16, m8_max, m4_max);
@@ -1186,13 +1199,20 @@ static int sdf_fwd_impl(const HmLevels &lv, const hm_mlp_desc *mlp, const float 
             if (e == hipSuccess)
                 e = hipFuncSetAttribute(reinterpret_cast<const void *>(sdf_fwd_p32_kernel<HM_FRAC_TRILINEAR>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(sdf_fwd_p32_kernel<kFracEmb>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
             if (e != hipSuccess) return hm_fail(HM_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
             attr32_done = true;
         }
         const int64_t tiles = (n + kPts32 - 1) / kPts32;
         const int64_t cap = max_workgroups > 0 ? max_workgroups : 512;   // two resident workgroups per CU
         const int64_t grid = tiles < cap ? tiles : cap;
-        if (frac_mode == HM_FRAC_REFERENCE)
+        if (mode == kFracEmb)
+            hipLaunchKernelGGL(sdf_fwd_p32_kernel<kFracEmb>, dim3((unsigned)grid), dim3(kThreads32), lds32,
+                               as_stream(stream), lv, net, x, n, table, B_fourier, out, out_stride, out_cols, n_dev,
+                               lo64, hi64);
+        else if (mode == HM_FRAC_REFERENCE)
             hipLaunchKernelGGL(sdf_fwd_p32_kernel<HM_FRAC_REFERENCE>, dim3((unsigned)grid), dim3(kThreads32), lds32,
                                as_stream(stream), lv, net, x, n, table, B_fourier, out, out_stride, out_cols, n_dev,
                                lo64, hi64);
@@ -1209,7 +1229,11 @@ static int sdf_fwd_impl(const HmLevels &lv, const hm_mlp_desc *mlp, const float 
         const int64_t tiles = (n + kPts - 1) / kPts;
         const int64_t cap = max_workgroups > 0 ? max_workgroups : 256;
         const int64_t grid = tiles < cap ? tiles : cap;
-        if (frac_mode == HM_FRAC_REFERENCE)
+        if (mode == kFracEmb)
+            hipLaunchKernelGGL(sdf_fwd_kernel<kFracEmb>, dim3((unsigned)grid), dim3(kThreadsSdf), lds,
+                               as_stream(stream), lv, net, x, n, table, B_fourier, out, out_stride, out_cols, n_dev,
+                               lo64, hi64);
+        else if (mode == HM_FRAC_REFERENCE)
             hipLaunchKernelGGL(sdf_fwd_kernel<HM_FRAC_REFERENCE>, dim3((unsigned)grid), dim3(kThreadsSdf), lds,
                                as_stream(stream), lv, net, x, n, table, B_fourier, out, out_stride, out_cols, n_dev,
                                lo64, hi64);
