@@ -231,6 +231,59 @@ def mlp_roofline(net, log2_n=18, iters=5, warmup=2):
             "points_per_s": round(n / (avg_ms * 1e-3), 1)}
 
 
+def gemm_roofline(device, iters=20, warmup=3):
+    """Exact-fp32 GEMM of the grad path (csrc/hm_gemm.hip) on the shapes one training step runs ~105 times: forward
+    X W^T (+ Softplus epilogue), input gradient dY W, weight gradient [u; z-bar]^T [v-bar; a] at 3072 / 2048 rows.
+    `achieved` = flops of the whole shape list / its time."""
+    from hashmodnffbanks_idr_amd import ops
+    shapes = []
+    for rows in (3072, 2048):
+        shapes += [(rows, 512, 512, False, True, True), (rows, 512, 512, False, False, False),
+                   (512, 512, 2 * rows, True, False, False)]
+    ops_list, flops = [], 0.0
+    for (M, N, K, ta, tb, sp) in shapes:
+        a = torch.randn((K, M) if ta else (M, K), device=device)
+        b = torch.randn((N, K) if tb else (K, N), device=device)
+        out = torch.empty(M, N, device=device)
+        bias = torch.zeros(N, device=device) if sp else None
+        if sp:
+            fn = (lambda a=a, b=b, bias=bias: ops.gemm_ep(a, b, bias, False, True, ops.EPI_SOFTPLUS, 100.0, 20.0))
+        else:
+            fn = (lambda a=a, b=b, ta=ta, tb=tb, out=out: ops.gemm(a, b, None, ta, tb, out=out))
+        ops_list.append(fn)
+        flops += 2.0 * M * N * K
+    per_shape = []
+    side = torch.cuda.Stream()
+    for fn, sh in zip(ops_list, shapes):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        # `iters` launches replayed from one HIP graph: the host cost of a launch (output allocation, ctypes call)
+        # is out of the picture, as it is in the captured training step
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(iters):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        s0, e0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s0.record()
+        g.replay()
+        e0.record()
+        torch.cuda.synchronize()
+        us = s0.elapsed_time(e0) / iters * 1e3
+        per_shape.append({"M": sh[0], "N": sh[1], "K": sh[2], "transA": sh[3], "transB": sh[4],
+                          "softplus_epilogue": sh[5], "us": round(us, 2),
+                          "TFLOP/s": round(2.0 * sh[0] * sh[1] * sh[2] / us / 1e6, 1)})
+        del g
+    total_us = sum(p["us"] for p in per_shape)
+    tf = flops / total_us / 1e6
+    return {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+            "frac": round(tf / MFMA_F32_PEAK_TF, 4), "traffic": None,
+            "kernel": "gemm_f32_pipe2_kernel (20 launches per shape replayed from a HIP graph, launch gaps included)",
+            "shapes": per_shape}
+
+
 def mlp_bf16_roofline(net, log2_n=18, iters=5, warmup=2):
     """bf16 coarse-search variant of the fused SDF kernel: same flop count, dense bf16 MFMA peak (2.5 PFLOP/s)."""
     from hashmodnffbanks_idr_amd import ops
@@ -426,7 +479,7 @@ def main():
     ap.add_argument("--calib", default="1,0", help="gather_calib: lanes per 128-B block, byte stride between them")
     ap.add_argument("--bf16", type=int, default=-1,
                     help="1: the ray tracer's coarse scans on the bf16 kernel (default for --cfg C5 = BASELINE configs[4])")
-    ap.add_argument("--only", choices=["gather", "gather_bwd", "mlp", "mlp_bf16", "gather_calib"], default=None,
+    ap.add_argument("--only", choices=["gather", "gather_bwd", "mlp", "mlp_bf16", "gemm", "gather_calib"], default=None,
                     help="profiling helper: run just one kernel section on cuda:0 and print its object")
     ap.add_argument("--cfg", default=None,
                     help="hash-grid config (tests/golden/params.py): default C2 = BASELINE configs[1]; C4 = configs[3] "
@@ -459,6 +512,8 @@ def main():
             print(json.dumps(gather_bwd_roofline(emb, args.gather_log2n)))
         elif args.only == "mlp_bf16":
             print(json.dumps(mlp_bf16_roofline(model.implicit_network)))
+        elif args.only == "gemm":
+            print(json.dumps(gemm_roofline(dev)))
         else:
             print(json.dumps(mlp_roofline(model.implicit_network)))
         return
@@ -569,6 +624,7 @@ def main():
                 line["roofline_c4"] = gather_roofline(emb4, args.gather_log2n)
                 del emb4
             line["roofline_mlp_bf16"] = mlp_bf16_roofline(_build(cfg, device, 0.0).implicit_network)
+            line["roofline_gemm"] = gemm_roofline(device)
             line["cpu_baseline"] = cpu_baseline(head_model)
             if world == 1:     # BASELINE configs[2] and [4] (filter-bank embedders), short legs beside the headline
                 line["config3_leg"] = _side_leg("C3", device, False)
