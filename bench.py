@@ -394,7 +394,7 @@ def _build(cfg, device, lr):
     return model
 
 
-def _side_leg(cfg, device, bf16, steps=6, warmup=3):
+def _side_leg(cfg, device, bf16, steps=6, warmup=3, sampler_head=0):
     """short fixed-weights leg of another BASELINE configuration on rank 0 (reported beside the headline)"""
     import types
     from hashmodnffbanks_idr_amd.model.loss import IDRLoss
@@ -403,13 +403,16 @@ def _side_leg(cfg, device, bf16, steps=6, warmup=3):
     a = types.SimpleNamespace(no_graph=False, warmup=warmup, steps=steps, rays=rays)
     model = _build(cfg, device, 0.0)
     model.implicit_network.bf16_coarse_search = bool(bf16)
-    model.ray_tracer.sampler_head = 0      # like the headline: the reference's evaluation count
+    model.ray_tracer.sampler_head = sampler_head      # 0, like the headline: the reference's evaluation count
     inp, gt = synthetic_batch(1234, rays, device)
     torch.manual_seed(100)
     dt, stats, final_loss, mode = _run_leg(a, model, ClipAdam(model.parameters(), lr=0.0, max_norm=1.0),
                                            IDRLoss(eikonal_weight=0.1, mask_weight=100.0, alpha=50.0), None, inp, gt, 1,
                                            device, 0)
     et, L, T = NFFB_CONFIGS[cfg][0], NFFB_CONFIGS[cfg][1], NFFB_CONFIGS[cfg][2]
+    if sampler_head:
+        return {"value": round(rays * steps / dt, 1), "unit": "rays/s", "ms_per_step": round(dt / steps * 1e3, 3),
+                "sampler_head": sampler_head, "sdf_evals_per_step": stats}
     return {"value": round(rays * steps / dt, 1), "unit": "rays/s", "ms_per_step": round(dt / steps * 1e3, 3),
             "steps": steps, "rays": rays, "workload": f"{et} embedder L={L} T=2^{T} F=2, {rays} rays, weights at init (lr = 0)",
             "dtype": "bf16 coarse ray-search scans, f32 elsewhere" if bf16 else "f32",
@@ -635,6 +638,8 @@ def main():
             line["roofline_gemm"] = gemm_roofline(device)
             line["cpu_baseline"] = cpu_baseline(head_model)
             if world == 1:     # BASELINE configs[2] and [4] (filter-bank embedders), short legs beside the headline
+                # (sampler_head = 16 changes nothing at these networks' initialisation: none of their sampler rays
+                #  has a sign change among the head samples, both passes run in full - 33.0 vs 32.5 ms at C3)
                 line["config3_leg"] = _side_leg("C3", device, False)
                 line["config5_leg"] = _side_leg("C5", device, True)
         print(json.dumps(line), flush=True)

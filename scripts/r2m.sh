@@ -9,5 +9,5 @@ print(d['value'], d['ms_per_step'], d['train_leg']['ms_per_step'])
 for k in ('roofline','roofline_c4','roofline_bwd','roofline_mlp','roofline_mlp_bf16'):
     print(k, d[k]['achieved'], d[k]['frac'], d[k].get('traffic'))
 print('cpu', d['cpu_baseline']['value'], d['cpu_baseline']['cores'])
-for k in ('config3_leg','config5_leg','lazy_sampler_leg'): print(k, d[k]['value'], d[k]['ms_per_step'])
+for k in ('config3_leg','config5_leg','lazy_sampler_leg'): print(k, d[k]['value'], d[k]['ms_per_step'], d[k].get('lazy_sampler',{}).get('ms_per_step'))
 PY
