@@ -206,7 +206,7 @@ def gather_bwd_roofline(emb, log2_n=22, iters=10, warmup=3, frac_mode=0):
     return rec
 
 
-def mlp_roofline(net, log2_n=18, iters=5, warmup=2):
+def mlp_roofline(net, log2_n=18, iters=10, warmup=4):
     """Fused SDF forward (encode + 9 MFMA layers), sdf-only output: 2*1 966 592 flop per point."""
     dev = next(net.parameters()).device
     n = 1 << log2_n
@@ -228,7 +228,7 @@ def mlp_roofline(net, log2_n=18, iters=5, warmup=2):
     return {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
             "frac": round(tf / MFMA_F32_PEAK_TF, 4), "traffic": None, "kernel": "sdf_fwd_kernel",
             "units_per_launch": n, "flop_per_unit": flops, "avg_launch_ms": round(avg_ms, 4),
-            "points_per_s": round(n / (avg_ms * 1e-3), 1)}
+            "min_launch_ms": round(float(ms.min()), 4), "points_per_s": round(n / (avg_ms * 1e-3), 1)}
 
 
 def gemm_roofline(device, iters=20, warmup=3):
