@@ -136,7 +136,116 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 
 }  // namespace
 
+// ---- SIREN activation sin(w0 x) (embeddings/Sine.py:10-12) and NeRF positional encoding (frequency_enc.py:6-51) with
+// their first / second order passes - the filter-bank embedders' grad path spends a third of its launches on the torch
+// expressions of these two (per layer: mul, sin | cos, mul, mul | ~8 more; per chunk: 12 x (mul, sin / cos), cat, ...)
+__global__ __launch_bounds__(kET) void sine_kernel(int order, const float *__restrict__ x, const float *__restrict__ gy,
+                                                   const float *__restrict__ gg, float *__restrict__ out0,
+                                                   float *__restrict__ out1, int64_t n, float w0) {
+    const int64_t i = (int64_t)blockIdx.x * kET + threadIdx.x;
+    if (i >= n) return;
+    const float u = __fmul_rn(x[i], w0);     // torch.sin(input * w0): fp32 product first
+    if (order == 0) {
+        out0[i] = sinf(u);
+    } else if (order == 1) {
+        out0[i] = __fmul_rn(__fmul_rn(gy[i], cosf(u)), w0);          // (gy * cos(u)) * w0, autograd's order
+    } else {
+        float sn, cs;
+        sincosf(u, &sn, &cs);
+        out0[i] = __fmul_rn(__fmul_rn(gg[i], w0), cs);               // d/d gy
+        out1[i] = -__fmul_rn(__fmul_rn(__fmul_rn(gg[i], w0), gy[i]), __fmul_rn(sn, w0));   // d/d x
+    }
+}
+
+struct PosEncArgs {
+    float freq[16];
+    int32_t n_freq, dim;
+};
+
+// rows [c | c | sin(f0 c) | cos(f0 c) | sin(f1 c) | ...], width 2 dim + 2 n_freq dim (the reference's embed() lists the
+// input twice when include_input is set); one thread per (row, component)
+__global__ __launch_bounds__(kET) void posenc_kernel(int order, PosEncArgs a, const float *__restrict__ c, int64_t ldc,
+                                                     const float *__restrict__ g, int64_t ldg,
+                                                     const float *__restrict__ gg, float *__restrict__ out0,
+                                                     int64_t ld0, float *__restrict__ out1, int64_t n) {
+    const int64_t t = (int64_t)blockIdx.x * kET + threadIdx.x;
+    const int D = a.dim;
+    const int64_t i = t / D;
+    const int d = (int)(t - i * D);
+    if (i >= n) return;
+    const float v = c[i * ldc + d];
+    if (order == 0) {
+        float *o = out0 + i * ld0;
+        o[d] = v;
+        o[D + d] = v;
+        for (int k = 0; k < a.n_freq; ++k) {
+            float sn, cs;
+            sincosf(__fmul_rn(v, a.freq[k]), &sn, &cs);
+            o[2 * D + 2 * k * D + d] = sn;
+            o[2 * D + (2 * k + 1) * D + d] = cs;
+        }
+    } else if (order == 1) {
+        const float *gr = g + i * ldg;
+        float acc = gr[d] + gr[D + d];
+        for (int k = 0; k < a.n_freq; ++k) {
+            float sn, cs;
+            sincosf(__fmul_rn(v, a.freq[k]), &sn, &cs);
+            acc += a.freq[k] * (cs * gr[2 * D + 2 * k * D + d] - sn * gr[2 * D + (2 * k + 1) * D + d]);
+        }
+        out0[i * ld0 + d] = acc;
+    } else {
+        // backward of order 1 along gg [n, D]: out0 = d/d g rows [n, W], out1 = d/d c [n, D]
+        const float *gr = g + i * ldg;
+        const float q = gg[i * D + d];
+        float *o = out0 + i * ld0;
+        o[d] = q;
+        o[D + d] = q;
+        float acc = 0.0f;
+        for (int k = 0; k < a.n_freq; ++k) {
+            float sn, cs;
+            sincosf(__fmul_rn(v, a.freq[k]), &sn, &cs);
+            const float f = a.freq[k];
+            o[2 * D + 2 * k * D + d] = q * f * cs;
+            o[2 * D + (2 * k + 1) * D + d] = -(q * f * sn);
+            acc += f * f * (sn * gr[2 * D + 2 * k * D + d] + cs * gr[2 * D + (2 * k + 1) * D + d]);
+        }
+        out1[i * D + d] = -(q * acc);
+    }
+}
+
 extern "C" {
+
+int hm_sine(int order, const float *x, const float *gy, const float *gg, float *out0, float *out1, int64_t n, float w0,
+            void *stream) {
+    HM_CHECK_ARG(order >= 0 && order <= 2, "hm_sine: order must be 0 (forward), 1 (backward) or 2 (double backward)");
+    HM_CHECK_ARG(n >= 0, "hm_sine: n < 0");
+    if (n == 0) return HM_OK;
+    HM_CHECK_ARG(x && out0 && (order == 0 || gy) && (order < 2 || (gg && out1)), "hm_sine: NULL pointer");
+    hipLaunchKernelGGL(sine_kernel, dim3((unsigned)((n + kET - 1) / kET)), dim3(kET), 0, as_stream(stream), order, x, gy,
+                       gg, out0, out1, n, w0);
+    HM_CHECK_LAUNCH("hm_sine");
+    return HM_OK;
+}
+
+int hm_posenc(int order, const float *freqs, int n_freq, int dim, const float *c, int64_t c_stride, const float *g,
+              int64_t g_stride, const float *gg, float *out0, int64_t out0_stride, float *out1, int64_t n, void *stream) {
+    HM_CHECK_ARG(order >= 0 && order <= 2, "hm_posenc: order must be 0 (forward), 1 (backward) or 2 (double backward)");
+    HM_CHECK_ARG(n >= 0 && n_freq >= 1 && n_freq <= 16 && dim >= 1 && dim <= 64, "hm_posenc: bad shape");
+    const int width = 2 * dim + 2 * n_freq * dim;
+    HM_CHECK_ARG(c_stride >= dim, "hm_posenc: c_stride < dim");
+    HM_CHECK_ARG(order == 0 || g_stride >= width, "hm_posenc: g_stride < row width");
+    HM_CHECK_ARG(out0_stride >= (order == 1 ? dim : width), "hm_posenc: out0_stride too small");
+    if (n == 0) return HM_OK;
+    HM_CHECK_ARG(freqs && c && out0 && (order == 0 || g) && (order < 2 || (gg && out1)), "hm_posenc: NULL pointer");
+    PosEncArgs a;
+    for (int k = 0; k < 16; ++k) a.freq[k] = k < n_freq ? freqs[k] : 0.0f;   // (host array)
+    a.n_freq = n_freq; a.dim = dim;
+    const int64_t threads = n * dim;
+    hipLaunchKernelGGL(posenc_kernel, dim3((unsigned)((threads + kET - 1) / kET)), dim3(kET), 0, as_stream(stream), order,
+                       a, c, c_stride, g, g_stride, gg, out0, out0_stride, out1, n);
+    HM_CHECK_LAUNCH("hm_posenc");
+    return HM_OK;
+}
 
 int hm_softplus(int order, const float *z, const float *gy, const float *gg, float *out0, float *out1, int64_t n,
                 float beta, float threshold, void *stream) {

@@ -13,6 +13,11 @@ class Sine(nn.Module):
         self.w0 = w0
 
     def forward(self, input, compute_grad=False):
+        if input.is_cuda and input.dtype == torch.float32 and input.requires_grad and torch.is_grad_enabled():
+            # grad path of the filter-bank trunk: one kernel per pass (forward, backward, double backward) instead
+            # of autograd's chain of mul / sin / cos / neg kernels
+            from ... import ops
+            return ops.sine(input, self.w0)
         return torch.sin(input * self.w0)
 
 

@@ -49,6 +49,13 @@ class PositionalEncoding(nn.Module):
         self.embeddings_dim = self.out_dim + d if self.include_input else self.out_dim
 
     def embed(self, inputs):
+        if (self.include_input and inputs.is_cuda and inputs.dtype == torch.float32 and inputs.dim() == 2
+                and inputs.requires_grad and torch.is_grad_enabled() and len(self.freq_bands) <= 16
+                and list(self.periodic_fns) == [torch.sin, torch.cos]):
+            # grad path of the filter-bank embedders: the whole row and its first / second order passes are one kernel
+            # each (csrc/hm_elem.hip) instead of ~26 / ~40 / ~60 elementwise launches per chunk
+            from ... import ops
+            return ops.posenc(inputs, self.freq_bands.tolist())
         parts = [inputs] if self.include_input else []
         for freq in self.freq_bands:
             for fn in self.periodic_fns:

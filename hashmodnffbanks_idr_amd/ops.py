@@ -843,6 +843,104 @@ class _SoftplusBwd(torch.autograd.Function):
         return d_z, d_gy, None, None
 
 
+def _sine_call(order, x, gy, gg, w0):
+    out0 = torch.empty_like(x)
+    out1 = torch.empty_like(x) if order == 2 else None
+    check(lib().hm_sine(order, dptr(x), dptr(gy), dptr(gg), dptr(out0), dptr(out1), x.numel(), float(w0), stream_ptr(x)))
+    return out0, out1
+
+
+class _Sine(torch.autograd.Function):
+    """sin(w0 x) (SIREN activation) with one-kernel backward and double backward (csrc/hm_elem.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, w0):
+        x = x.contiguous()
+        ctx.w0 = w0
+        ctx.save_for_backward(x)
+        return _sine_call(0, x, None, None, w0)[0]
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        return _SineBwd.apply(x, gy, ctx.w0), None
+
+
+class _SineBwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gy, w0):
+        gy = gy.contiguous()
+        ctx.w0 = w0
+        ctx.save_for_backward(x, gy)
+        return _sine_call(1, x, gy, None, w0)[0]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gg):
+        x, gy = ctx.saved_tensors
+        d_gy, d_x = _sine_call(2, x, gy, gg.contiguous(), ctx.w0)
+        return d_x, d_gy, None
+
+
+def sine(x, w0):
+    """sin(w0 * x), differentiable twice (third order is not provided)."""
+    require_gpu(x)
+    return _Sine.apply(x, float(w0))
+
+
+def _posenc_call(order, freqs, c, g, gg):
+    n, D = c.shape
+    W = 2 * D + 2 * len(freqs) * D
+    fa = (C.c_float * len(freqs))(*freqs)
+    out0 = torch.empty((n, D if order == 1 else W), dtype=torch.float32, device=c.device)
+    out1 = torch.empty((n, D), dtype=torch.float32, device=c.device) if order == 2 else None
+    check(lib().hm_posenc(order, C.cast(fa, C.c_void_p), len(freqs), D, dptr(c), _ld(c), dptr(g),
+                          _ld(g) if g is not None else 0, dptr(gg), dptr(out0), out0.stride(0), dptr(out1), n,
+                          stream_ptr(c)))
+    return out0, out1
+
+
+class _PosEnc(torch.autograd.Function):
+    """[c | c | sin(f0 c) | cos(f0 c) | ...] (NeRF positional encoding as the reference builds it with include_input)
+    with one-kernel backward and double backward (csrc/hm_elem.hip)."""
+
+    @staticmethod
+    def forward(ctx, c, freqs):
+        c = _rowmajor(c)
+        ctx.freqs = freqs
+        ctx.save_for_backward(c)
+        return _posenc_call(0, freqs, c, None, None)[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (c,) = ctx.saved_tensors
+        return _PosEncBwd.apply(c, g, ctx.freqs), None
+
+
+class _PosEncBwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, c, g, freqs):
+        g = _rowmajor(g)
+        ctx.freqs = freqs
+        ctx.save_for_backward(c, g)
+        return _posenc_call(1, freqs, c, g, None)[0]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gg):
+        c, g = ctx.saved_tensors
+        d_g, d_c = _posenc_call(2, ctx.freqs, c, g, gg.contiguous())
+        return d_c, d_g, None
+
+
+def posenc(c, freqs):
+    """NeRF positional encoding rows (include_input form of the reference), differentiable twice."""
+    require_gpu(c)
+    if c.dim() != 2 or c.dtype != torch.float32:
+        raise ValueError("hashmod posenc: [N, D] fp32 input")
+    return _PosEnc.apply(c, tuple(float(f) for f in freqs))
+
+
 def softplus(z, beta=100.0, threshold=20.0):
     """nn.Softplus(beta, threshold) with fused backward and double backward (third order is not provided)."""
     require_gpu(z)

@@ -373,6 +373,21 @@ HM_API int hm_gemm_f32_ep(int transA, int transB, int64_t M, int64_t N, int64_t 
 HM_API int hm_softplus(int order, const float *z, const float *gy, const float *gg, float *out0, float *out1,
                        int64_t n, float beta, float threshold, void *stream);
 
+/* The same three passes for the two elementwise pieces of the Fourier-filter-bank embedders (BASELINE configs 3 / 5):
+ *   hm_sine    SIREN activation y = sin(w0 x) (embeddings/Sine.py:10-12) over n floats:
+ *                order 0: out0 = sin(w0 x);  order 1: out0 = gy w0 cos(w0 x);
+ *                order 2: out0 = gg w0 cos(w0 x) (d/d gy),  out1 = -gg gy w0^2 sin(w0 x) (d/d x)
+ *   hm_posenc  NeRF positional encoding of rows c [n, dim] (frequency_enc.py:6-51 with include_input, sin / cos,
+ *              `freqs` = HOST array of n_freq bands): row = [c | c | sin(f0 c) | cos(f0 c) | sin(f1 c) | ...],
+ *              width W = 2 dim + 2 n_freq dim:
+ *                order 0: out0 [n, W] = row;   order 1: out0 [n, dim] = (d row / d c)^T g  (g [n, W]);
+ *                order 2 (given gg [n, dim] contiguous): out0 [n, W] = d(gg . order1)/d g,  out1 [n, dim] = d(gg . order1)/d c */
+HM_API int hm_sine(int order, const float *x, const float *gy, const float *gg, float *out0, float *out1, int64_t n,
+                   float w0, void *stream);
+HM_API int hm_posenc(int order, const float *freqs, int n_freq, int dim, const float *c, int64_t c_stride,
+                     const float *g, int64_t g_stride, const float *gg, float *out0, int64_t out0_stride, float *out1,
+                     int64_t n, void *stream);
+
 /* Soft clamp of the SDF column of the last layer's output zL [n, cols] (contiguous) and its backward
  * (implicit_differentiable_renderer.py:112, density_net.py:20-30; the density is evaluated without gradient):
  *   backward == 0:  out = zL with column 0 -> sdf = tanh(s / (2 + rho(s)));  sdf, denom = 2 + rho, c = d sdf/d s [n]

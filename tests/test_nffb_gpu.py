@@ -134,3 +134,47 @@ def test_fused_sdf_and_device_tracer_on_nffb(golden, tag, et):
             assert st["unfinished"] == 0 and st["nonfinite"] == 0 and st["sdf_evals"] > 600
     (p1, m1, d1), (p2, m2, d2) = outs
     assert torch.equal(m1, m2) and torch.equal(d1, d2) and torch.equal(p1, p2)
+
+
+def _second_order_check(name, fused, plain, x0, extra=()):
+    """values, d/dx with create_graph and the backward of a loss on that gradient: fused op vs torch's autograd over the
+    elementwise expression"""
+    g = torch.Generator(device="cpu").manual_seed(3)
+    outs = []
+    for fn in (fused, plain):
+        x = x0.clone().requires_grad_(True)
+        y = fn(x)
+        m = torch.randn(y.shape, generator=torch.Generator(device="cpu").manual_seed(4)).cuda().requires_grad_(True)
+        (gx,) = torch.autograd.grad((y * m).sum(), x, create_graph=True)
+        r = torch.randn(gx.shape, generator=torch.Generator(device="cpu").manual_seed(5)).cuda()
+        ((gx * r).pow(2).sum() + 0.1 * y.pow(2).sum()).backward()
+        outs.append((y.detach(), gx.detach(), x.grad, m.grad))
+    for what, a, b in zip(("value", "d/dx", "loss d/dx", "loss d/dm"), outs[0], outs[1]):
+        scale = b.abs().max().item()
+        err = (a - b).abs().max().item()
+        print(f"{name} {what}: max |d| {err:.3e} (scale {scale:.3e})")
+        assert scale > 0 and err <= 2e-5 * scale, (name, what)
+
+
+def test_sine_activation_op_matches_torch_autograd():
+    from hashmodnffbanks_idr_amd import ops
+    x0 = (torch.rand((4000, 56), generator=torch.Generator(device="cpu").manual_seed(1)) * 2 - 1).cuda() * 0.3
+    _second_order_check("sine w0=30", lambda x: ops.sine(x, 30.0), lambda x: torch.sin(x * 30.0), x0)
+
+
+@pytest.mark.parametrize("n_freq", [6, 8])
+def test_positional_encoding_op_matches_torch_autograd(n_freq):
+    from hashmodnffbanks_idr_amd.model.embeddings.frequency_enc import PositionalEncoding
+    pe = PositionalEncoding(include_input=True, input_dims=4, max_freq_log2=n_freq - 1, num_freqs=n_freq,
+                            log_sampling=True, periodic_fns=[torch.sin, torch.cos])
+    wide = (torch.rand((3000, 24), generator=torch.Generator(device="cpu").manual_seed(2)) * 2 - 1).cuda()
+
+    def plain(c):
+        parts = [c]
+        for f in pe.freq_bands:
+            parts += [torch.sin(c * f), torch.cos(c * f)]
+        return torch.cat([c, torch.cat(parts, -1)], -1)
+
+    # a strided [N, 4] chunk of a wider row, as FourierFilterBanks hands it over
+    _second_order_check(f"posenc L={n_freq}", lambda x: pe.embed(x[:, 8:12]), lambda x: plain(x[:, 8:12]), wide)
+    assert pe.embed(wide[:, :4].clone().requires_grad_(True)).shape[1] == pe.embeddings_dim
