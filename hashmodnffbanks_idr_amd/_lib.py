@@ -40,6 +40,7 @@ SIGNATURES = {
     "hm_encode_bwd_table_jvp": (_int, [_p, _p, _i64, _p, _p, _i64, _p, _p]),
     "hm_fourier_bwd_input": (_int, [_p, _i64, _p, _int, _p, _i64, _p, _p]),
     "hm_fourier_bwd_input_bwd": (_int, [_p, _i64, _p, _int, _p, _i64, _p, _p, _p, _i64, _int, _p]),
+    "hm_rownorm": (_int, [_int, _p, _p, _p, _p, _p, _i64, _int, C.c_float, _p]),
     "hm_sine": (_int, [_int, _p, _p, _p, _p, _p, _i64, C.c_float, _p]),
     "hm_posenc": (_int, [_int, _p, _int, _int, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p]),
     "hm_sdf_fwd": (_int, [_p, _p, _p, _i64, _p, _p, _p, _i64, _int, _int, _int, _p, _int, _p]),

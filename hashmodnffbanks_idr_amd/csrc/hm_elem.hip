@@ -213,7 +213,80 @@ __global__ __launch_bounds__(kET) void posenc_kernel(int order, PosEncArgs a, co
     }
 }
 
+// ---- per-row normalisation (y - mean) / sqrt(var + eps), biased variance: what nn.InstanceNorm1d does to the 2-D tensor
+// StyleAttention hands it (style_Attention/styleMod.py:41-43), with its first / second order passes.
+//   F(y, g)   = (g - mean(g) - yh mean(g yh)) / sigma          (backward; yh = normalised row; linear and symmetric in g)
+//   order 2   : d/dg (gg . F) = F(y, gg);   d/dy_j (gg . F) = -[ yh_j (a - b c / n) + c (gg_j - mean(gg) - yh_j b / n)
+//                                                                + b (g_j - mean(g) - yh_j c / n) ] / (n sigma^2)
+//               with a = sum(gg g) - sum(gg) sum(g) / n,  b = sum(gg yh),  c = sum(g yh)
+// One thread per row (rows are 56 / 72 floats; a step normalises ~50 k rows).
+__global__ __launch_bounds__(kET) void rownorm_kernel(int order, const float *__restrict__ y, const float *__restrict__ g,
+                                                      const float *__restrict__ gg, float *__restrict__ out0,
+                                                      float *__restrict__ out1, int64_t rows, int W, float eps) {
+    const int64_t r = (int64_t)blockIdx.x * kET + threadIdx.x;
+    if (r >= rows) return;
+    const float *yr = y + r * W;
+    const float inv_n = 1.0f / (float)W;
+    float mean = 0.0f;
+    for (int k = 0; k < W; ++k) mean += yr[k];
+    mean *= inv_n;
+    float var = 0.0f;
+    for (int k = 0; k < W; ++k) {
+        const float d = yr[k] - mean;
+        var += d * d;
+    }
+    var *= inv_n;
+    const float sigma = sqrtf(var + eps);
+    const float rs = 1.0f / sigma;
+    if (order == 0) {
+        for (int k = 0; k < W; ++k) out0[r * W + k] = (yr[k] - mean) / sigma;
+        return;
+    }
+    const float *gr = g + r * W;
+    float sg = 0.0f, c = 0.0f;
+    for (int k = 0; k < W; ++k) {
+        const float yh = (yr[k] - mean) * rs;
+        sg += gr[k];
+        c += gr[k] * yh;
+    }
+    if (order == 1) {
+        for (int k = 0; k < W; ++k) {
+            const float yh = (yr[k] - mean) * rs;
+            out0[r * W + k] = (gr[k] - sg * inv_n - yh * c * inv_n) * rs;
+        }
+        return;
+    }
+    const float *qr = gg + r * W;
+    float sq = 0.0f, b = 0.0f, a = 0.0f;
+    for (int k = 0; k < W; ++k) {
+        const float yh = (yr[k] - mean) * rs;
+        sq += qr[k];
+        b += qr[k] * yh;
+        a += qr[k] * gr[k];
+    }
+    a -= sq * sg * inv_n;
+    const float t = a - b * c * inv_n;
+    const float k2 = rs * rs * inv_n;
+    for (int k = 0; k < W; ++k) {
+        const float yh = (yr[k] - mean) * rs;
+        out0[r * W + k] = (qr[k] - sq * inv_n - yh * b * inv_n) * rs;
+        out1[r * W + k] = -k2 * (yh * t + c * (qr[k] - sq * inv_n - yh * b * inv_n) + b * (gr[k] - sg * inv_n - yh * c * inv_n));
+    }
+}
+
 extern "C" {
+
+int hm_rownorm(int order, const float *y, const float *g, const float *gg, float *out0, float *out1, int64_t rows,
+               int width, float eps, void *stream) {
+    HM_CHECK_ARG(order >= 0 && order <= 2, "hm_rownorm: order must be 0 (forward), 1 (backward) or 2 (double backward)");
+    HM_CHECK_ARG(rows >= 0 && width >= 1 && width <= 4096, "hm_rownorm: bad shape");
+    if (rows == 0) return HM_OK;
+    HM_CHECK_ARG(y && out0 && (order == 0 || g) && (order < 2 || (gg && out1)), "hm_rownorm: NULL pointer");
+    hipLaunchKernelGGL(rownorm_kernel, dim3((unsigned)((rows + kET - 1) / kET)), dim3(kET), 0, as_stream(stream), order, y,
+                       g, gg, out0, out1, rows, width, eps);
+    HM_CHECK_LAUNCH("hm_rownorm");
+    return HM_OK;
+}
 
 int hm_sine(int order, const float *x, const float *gy, const float *gg, float *out0, float *out1, int64_t n, float w0,
             void *stream) {

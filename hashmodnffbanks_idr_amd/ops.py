@@ -888,6 +888,54 @@ def sine(x, w0):
     return _Sine.apply(x, float(w0))
 
 
+def _rownorm_call(order, y, g, gg, eps):
+    out0 = torch.empty_like(y)
+    out1 = torch.empty_like(y) if order == 2 else None
+    check(lib().hm_rownorm(order, dptr(y), dptr(g), dptr(gg), dptr(out0), dptr(out1), y.shape[0], y.shape[1], float(eps),
+                           stream_ptr(y)))
+    return out0, out1
+
+
+class _RowNorm(torch.autograd.Function):
+    """(y - mean) / sqrt(var + eps) per row with one-kernel backward and double backward (csrc/hm_elem.hip)."""
+
+    @staticmethod
+    def forward(ctx, y, eps):
+        y = y.contiguous()
+        ctx.eps = eps
+        ctx.save_for_backward(y)
+        return _rownorm_call(0, y, None, None, eps)[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        return _RowNormBwd.apply(y, g, ctx.eps), None
+
+
+class _RowNormBwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, g, eps):
+        g = g.contiguous()
+        ctx.eps = eps
+        ctx.save_for_backward(y, g)
+        return _rownorm_call(1, y, g, None, eps)[0]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gg):
+        y, g = ctx.saved_tensors
+        d_g, d_y = _rownorm_call(2, y, g, gg.contiguous(), ctx.eps)
+        return d_y, d_g, None
+
+
+def rownorm(y, eps=1e-5):
+    """per-row normalisation of a [N, W] tensor (biased variance), differentiable twice."""
+    require_gpu(y)
+    if y.dim() != 2 or y.dtype != torch.float32:
+        raise ValueError("hashmod rownorm: [N, W] fp32 input")
+    return _RowNorm.apply(y, float(eps))
+
+
 def _posenc_call(order, freqs, c, g, gg):
     n, D = c.shape
     W = 2 * D + 2 * len(freqs) * D

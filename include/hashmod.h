@@ -382,6 +382,12 @@ HM_API int hm_softplus(int order, const float *z, const float *gy, const float *
  *              width W = 2 dim + 2 n_freq dim:
  *                order 0: out0 [n, W] = row;   order 1: out0 [n, dim] = (d row / d c)^T g  (g [n, W]);
  *                order 2 (given gg [n, dim] contiguous): out0 [n, W] = d(gg . order1)/d g,  out1 [n, dim] = d(gg . order1)/d c */
+/*   hm_rownorm  (y - mean) / sqrt(var + eps) per row of a contiguous [rows, width] tensor, biased variance - the
+ *              nn.InstanceNorm1d call of StyleAttention on a 2-D tensor (style_Attention/styleMod.py:41-43):
+ *                order 0: out0 = normalised rows;  order 1: out0 = its backward applied to g;
+ *                order 2 (given gg): out0 = d(gg . order1)/d g,  out1 = d(gg . order1)/d y                              */
+HM_API int hm_rownorm(int order, const float *y, const float *g, const float *gg, float *out0, float *out1, int64_t rows,
+                      int width, float eps, void *stream);
 HM_API int hm_sine(int order, const float *x, const float *gy, const float *gg, float *out0, float *out1, int64_t n,
                    float w0, void *stream);
 HM_API int hm_posenc(int order, const float *freqs, int n_freq, int dim, const float *c, int64_t c_stride,

@@ -178,3 +178,30 @@ def test_positional_encoding_op_matches_torch_autograd(n_freq):
     # a strided [N, 4] chunk of a wider row, as FourierFilterBanks hands it over
     _second_order_check(f"posenc L={n_freq}", lambda x: pe.embed(x[:, 8:12]), lambda x: plain(x[:, 8:12]), wide)
     assert pe.embed(wide[:, :4].clone().requires_grad_(True)).shape[1] == pe.embeddings_dim
+
+
+@pytest.mark.parametrize("W", [56, 72])
+def test_style_attention_fused_norm_matches_torch_autograd(W):
+    """StyleAttention (styleMod.py:30-43) on the grad path: ops.rownorm + exact-zero attention gradients against the torch
+    expression of the block (softmax over a size-1 dim, mean / var / sqrt / div), to second order; the attention Linear's
+    gradients are exact zeros on both routes"""
+    from hashmodnffbanks_idr_amd.model.embeddings.style_Attention.styleMod import StyleAttention
+    torch.manual_seed(0)
+    blk = StyleAttention(3, W).cuda()
+    content = (torch.rand((3000, 3), generator=torch.Generator(device="cpu").manual_seed(7))).cuda()
+    x0 = torch.randn((3000, W), generator=torch.Generator(device="cpu").manual_seed(8)).cuda()
+
+    def run(fused):
+        def f(x):
+            blk.fused_norm = fused
+            return blk(content, x)
+        return f
+
+    _second_order_check(f"StyleAttention W={W}", run(True), run(False), x0)
+    for fused in (True, False):
+        blk.fused_norm = fused
+        blk.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        blk(content, x).pow(2).sum().backward()
+        assert blk.attention.weight.grad is not None and float(blk.attention.weight.grad.abs().max()) == 0.0
+        assert blk.attention.bias.grad is not None and float(blk.attention.bias.grad.abs().max()) == 0.0
