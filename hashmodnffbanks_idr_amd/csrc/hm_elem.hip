@@ -219,58 +219,84 @@ __global__ __launch_bounds__(kET) void posenc_kernel(int order, PosEncArgs a, co
 //   order 2   : d/dg (gg . F) = F(y, gg);   d/dy_j (gg . F) = -[ yh_j (a - b c / n) + c (gg_j - mean(gg) - yh_j b / n)
 //                                                                + b (g_j - mean(g) - yh_j c / n) ] / (n sigma^2)
 //               with a = sum(gg g) - sum(gg) sum(g) / n,  b = sum(gg yh),  c = sum(g yh)
-// One thread per row (rows are 56 / 72 floats; a step normalises ~50 k rows).
+// Eight lanes per row (each keeps <= 16 of the row's values in registers; rows are 56 / 72 floats wide), sums by shuffles.
+constexpr int kRowLanes = 8, kRowMaxPerLane = 16;
+
+__device__ __forceinline__ float row_sum8(float v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    return v;
+}
+
 __global__ __launch_bounds__(kET) void rownorm_kernel(int order, const float *__restrict__ y, const float *__restrict__ g,
                                                       const float *__restrict__ gg, float *__restrict__ out0,
                                                       float *__restrict__ out1, int64_t rows, int W, float eps) {
-    const int64_t r = (int64_t)blockIdx.x * kET + threadIdx.x;
-    if (r >= rows) return;
-    const float *yr = y + r * W;
+    const int64_t t = (int64_t)blockIdx.x * kET + threadIdx.x;
+    int64_t r = t / kRowLanes;
+    const int sub = (int)(t % kRowLanes);
+    const bool live = r < rows;
+    if (!live) r = rows - 1;                     // keep the whole wave in the shuffles
+    const int cnt = (W - sub + kRowLanes - 1) / kRowLanes;      // this lane's elements: sub, sub + 8, ...
     const float inv_n = 1.0f / (float)W;
-    float mean = 0.0f;
-    for (int k = 0; k < W; ++k) mean += yr[k];
-    mean *= inv_n;
+    float yv[kRowMaxPerLane], gv[kRowMaxPerLane], qv[kRowMaxPerLane];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < kRowMaxPerLane; ++i) {
+        yv[i] = i < cnt ? y[r * W + sub + kRowLanes * i] : 0.0f;
+        s += yv[i];
+    }
+    const float mean = row_sum8(s) * inv_n;
     float var = 0.0f;
-    for (int k = 0; k < W; ++k) {
-        const float d = yr[k] - mean;
+#pragma unroll
+    for (int i = 0; i < kRowMaxPerLane; ++i) {
+        const float d = i < cnt ? yv[i] - mean : 0.0f;
         var += d * d;
     }
-    var *= inv_n;
+    var = row_sum8(var) * inv_n;
     const float sigma = sqrtf(var + eps);
     const float rs = 1.0f / sigma;
     if (order == 0) {
-        for (int k = 0; k < W; ++k) out0[r * W + k] = (yr[k] - mean) / sigma;
+#pragma unroll
+        for (int i = 0; i < kRowMaxPerLane; ++i)
+            if (live && i < cnt) out0[r * W + sub + kRowLanes * i] = (yv[i] - mean) / sigma;
         return;
     }
-    const float *gr = g + r * W;
     float sg = 0.0f, c = 0.0f;
-    for (int k = 0; k < W; ++k) {
-        const float yh = (yr[k] - mean) * rs;
-        sg += gr[k];
-        c += gr[k] * yh;
+#pragma unroll
+    for (int i = 0; i < kRowMaxPerLane; ++i) {
+        gv[i] = i < cnt ? g[r * W + sub + kRowLanes * i] : 0.0f;
+        yv[i] = i < cnt ? (yv[i] - mean) * rs : 0.0f;          // yh from here on
+        sg += gv[i];
+        c += gv[i] * yv[i];
     }
+    sg = row_sum8(sg);
+    c = row_sum8(c);
     if (order == 1) {
-        for (int k = 0; k < W; ++k) {
-            const float yh = (yr[k] - mean) * rs;
-            out0[r * W + k] = (gr[k] - sg * inv_n - yh * c * inv_n) * rs;
-        }
+#pragma unroll
+        for (int i = 0; i < kRowMaxPerLane; ++i)
+            if (live && i < cnt) out0[r * W + sub + kRowLanes * i] = (gv[i] - sg * inv_n - yv[i] * c * inv_n) * rs;
         return;
     }
-    const float *qr = gg + r * W;
     float sq = 0.0f, b = 0.0f, a = 0.0f;
-    for (int k = 0; k < W; ++k) {
-        const float yh = (yr[k] - mean) * rs;
-        sq += qr[k];
-        b += qr[k] * yh;
-        a += qr[k] * gr[k];
+#pragma unroll
+    for (int i = 0; i < kRowMaxPerLane; ++i) {
+        qv[i] = i < cnt ? gg[r * W + sub + kRowLanes * i] : 0.0f;
+        sq += qv[i];
+        b += qv[i] * yv[i];
+        a += qv[i] * gv[i];
     }
-    a -= sq * sg * inv_n;
-    const float t = a - b * c * inv_n;
+    sq = row_sum8(sq);
+    b = row_sum8(b);
+    a = row_sum8(a) - sq * sg * inv_n;
+    const float tt = a - b * c * inv_n;
     const float k2 = rs * rs * inv_n;
-    for (int k = 0; k < W; ++k) {
-        const float yh = (yr[k] - mean) * rs;
-        out0[r * W + k] = (qr[k] - sq * inv_n - yh * b * inv_n) * rs;
-        out1[r * W + k] = -k2 * (yh * t + c * (qr[k] - sq * inv_n - yh * b * inv_n) + b * (gr[k] - sg * inv_n - yh * c * inv_n));
+#pragma unroll
+    for (int i = 0; i < kRowMaxPerLane; ++i) {
+        if (!(live && i < cnt)) continue;
+        const float fq = qv[i] - sq * inv_n - yv[i] * b * inv_n, fg = gv[i] - sg * inv_n - yv[i] * c * inv_n;
+        out0[r * W + sub + kRowLanes * i] = fq * rs;
+        out1[r * W + sub + kRowLanes * i] = -k2 * (yv[i] * tt + c * fq + b * fg);
     }
 }
 
@@ -279,11 +305,11 @@ extern "C" {
 int hm_rownorm(int order, const float *y, const float *g, const float *gg, float *out0, float *out1, int64_t rows,
                int width, float eps, void *stream) {
     HM_CHECK_ARG(order >= 0 && order <= 2, "hm_rownorm: order must be 0 (forward), 1 (backward) or 2 (double backward)");
-    HM_CHECK_ARG(rows >= 0 && width >= 1 && width <= 4096, "hm_rownorm: bad shape");
+    HM_CHECK_ARG(rows >= 0 && width >= 1 && width <= kRowLanes * kRowMaxPerLane, "hm_rownorm: width must be 1 .. 128");
     if (rows == 0) return HM_OK;
     HM_CHECK_ARG(y && out0 && (order == 0 || g) && (order < 2 || (gg && out1)), "hm_rownorm: NULL pointer");
-    hipLaunchKernelGGL(rownorm_kernel, dim3((unsigned)((rows + kET - 1) / kET)), dim3(kET), 0, as_stream(stream), order, y,
-                       g, gg, out0, out1, rows, width, eps);
+    hipLaunchKernelGGL(rownorm_kernel, dim3((unsigned)((rows * kRowLanes + kET - 1) / kET)), dim3(kET), 0,
+                       as_stream(stream), order, y, g, gg, out0, out1, rows, width, eps);
     HM_CHECK_LAUNCH("hm_rownorm");
     return HM_OK;
 }
