@@ -40,6 +40,7 @@ SIGNATURES = {
     "hm_encode_bwd_table_jvp": (_int, [_p, _p, _i64, _p, _p, _i64, _p, _p]),
     "hm_fourier_bwd_input": (_int, [_p, _i64, _p, _int, _p, _i64, _p, _p]),
     "hm_fourier_bwd_input_bwd": (_int, [_p, _i64, _p, _int, _p, _i64, _p, _p, _p, _i64, _int, _p]),
+    "hm_weight_norm_multi": (_int, [_int, _int, _p, _p]),
     "hm_rownorm": (_int, [_int, _p, _p, _p, _p, _p, _i64, _int, C.c_float, _p]),
     "hm_sine": (_int, [_int, _p, _p, _p, _p, _p, _i64, C.c_float, _p]),
     "hm_posenc": (_int, [_int, _p, _int, _int, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p]),
@@ -93,6 +94,11 @@ class TraceCfg(C.Structure):
                 ("line_step_iters", C.c_int32), ("sphere_tracing_iters", C.c_int32), ("n_steps", C.c_int32),
                 ("n_secant_steps", C.c_int32), ("training", C.c_int32), ("coarse_bf16", C.c_int32),
                 ("sampler_head", C.c_int32)]
+
+
+class WnLayer(C.Structure):
+    _fields_ = [("v", C.c_void_p), ("g", C.c_void_p), ("w", C.c_void_p), ("norm", C.c_void_p), ("grad_w", C.c_void_p),
+                ("grad_v", C.c_void_p), ("grad_g", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32)]
 
 
 class NffbDesc(C.Structure):

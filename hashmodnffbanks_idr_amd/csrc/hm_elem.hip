@@ -300,7 +300,78 @@ __global__ __launch_bounds__(kET) void rownorm_kernel(int order, const float *__
     }
 }
 
+// ---- weight-norm fold of SEVERAL layers in one launch: W = g * v / ||v||_row (nn.utils.weight_norm, dim = 0) and its
+// backward - torch launches one _weight_norm kernel per layer and pass (14 layers: 23 + 14 launches per step).
+// Same arithmetic as ATen's weight_norm_fwd/bwd_first_dim kernels: w = (g v) (1/norm);
+// grad_g = <grad_w, v> / norm, grad_v = g (grad_w / norm - v <grad_w, v> / norm^3).  One workgroup per row.
+struct WnLayer {
+    const float *v, *g, *gw;    // [rows, cols], [rows], grad_w [rows, cols] (backward)
+    float *w, *norm, *gv, *gg;  // forward: w, norm [rows]; backward: grad_v, grad_g
+    int32_t rows, cols, row0, pad_;
+};
+struct WnTable {
+    WnLayer layer[HM_MAX_LAYERS * 2];
+    int32_t n;
+};
+
+__device__ __forceinline__ float wn_block_sum(float v, float *red) {   // 256 threads
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(kET) void weight_norm_multi_kernel(WnTable t, int backward) {
+    __shared__ float red[4];
+    int li = 0;
+    while (li + 1 < t.n && (int)blockIdx.x >= t.layer[li + 1].row0) ++li;
+    const WnLayer &L = t.layer[li];
+    const int row = (int)blockIdx.x - L.row0;
+    const float *v = L.v + (int64_t)row * L.cols;
+    if (!backward) {
+        float s = 0.0f;
+        for (int k = threadIdx.x; k < L.cols; k += kET) s += v[k] * v[k];
+        const float norm = sqrtf(wn_block_sum(s, red));
+        const float rnorm = 1.0f / norm, g = L.g[row];
+        if (threadIdx.x == 0) L.norm[row] = norm;
+        float *w = L.w + (int64_t)row * L.cols;
+        for (int k = threadIdx.x; k < L.cols; k += kET) w[k] = g * v[k] * rnorm;
+    } else {
+        const float *gw = L.gw + (int64_t)row * L.cols;
+        float s = 0.0f;
+        for (int k = threadIdx.x; k < L.cols; k += kET) s += gw[k] * v[k];
+        const float dot = wn_block_sum(s, red);
+        const float rnorm = 1.0f / L.norm[row], rnorm3 = rnorm * rnorm * rnorm, g = L.g[row];
+        if (threadIdx.x == 0) L.gg[row] = dot * rnorm;
+        float *gv = L.gv + (int64_t)row * L.cols;
+        for (int k = threadIdx.x; k < L.cols; k += kET) gv[k] = g * (rnorm * gw[k] - rnorm3 * v[k] * dot);
+    }
+}
+
 extern "C" {
+
+int hm_weight_norm_multi(int backward, int n_layers, const hm_wn_layer *layers, void *stream) {
+    HM_CHECK_ARG(n_layers >= 0 && n_layers <= HM_MAX_LAYERS * 2, "hm_weight_norm_multi: too many layers");
+    if (n_layers == 0) return HM_OK;
+    HM_CHECK_ARG(layers != nullptr, "hm_weight_norm_multi: NULL table");
+    WnTable t;
+    int row0 = 0;
+    for (int i = 0; i < n_layers; ++i) {
+        const hm_wn_layer &s = layers[i];
+        HM_CHECK_ARG(s.rows >= 1 && s.cols >= 1 && s.v && s.g && s.norm, "hm_weight_norm_multi: bad layer");
+        HM_CHECK_ARG(backward ? (s.grad_w && s.grad_v && s.grad_g) : (s.w != nullptr), "hm_weight_norm_multi: NULL pointer");
+        WnLayer &d = t.layer[i];
+        d.v = s.v; d.g = s.g; d.gw = s.grad_w; d.w = s.w; d.norm = s.norm; d.gv = s.grad_v; d.gg = s.grad_g;
+        d.rows = s.rows; d.cols = s.cols; d.row0 = row0; d.pad_ = 0;
+        row0 += s.rows;
+    }
+    t.n = n_layers;
+    hipLaunchKernelGGL(weight_norm_multi_kernel, dim3((unsigned)row0), dim3(kET), 0, as_stream(stream), t, backward);
+    HM_CHECK_LAUNCH("hm_weight_norm_multi");
+    return HM_OK;
+}
 
 int hm_rownorm(int order, const float *y, const float *g, const float *gg, float *out0, float *out1, int64_t rows,
                int width, float eps, void *stream) {

@@ -35,6 +35,20 @@ def _weight_normed(lin):
         return nn.utils.weight_norm(lin)
 
 
+def _fold_all(nets, cache):
+    """weight-norm fold of every Linear of `nets` in ONE launch (ops.weight_norm_fold; its backward is one launch too),
+    left in `cache` for _folded_weight - torch._weight_norm is one launch per layer and pass (23 + 14 per step)"""
+    lins = []
+    for net in nets:
+        for l in range(net.num_layers - 1):
+            lin = getattr(net, "lin" + str(l))
+            if hasattr(lin, "weight_g") and lin.weight_v.is_cuda and lin.weight_v.dtype == torch.float32:
+                lins.append(lin)
+    if lins and torch.is_grad_enabled():
+        for lin, w in zip(lins, ops.weight_norm_fold([lin.weight_v for lin in lins], [lin.weight_g for lin in lins])):
+            cache[id(lin)] = w
+
+
 def _folded_weight(lin, cache=None):
     """W = g * v / ||v||_row for weight-normed layers (nn.utils.weight_norm, dim=0), else lin.weight.
     `cache` (a dict living for ONE IDRNetwork.forward) shares the fold between the evaluations of a step."""
@@ -151,7 +165,12 @@ class ImplicitNetwork(nn.Module):
                 self._packed.has_bf16 != bool(self.bf16_coarse_search):
             self._force_repack = False
             with torch.no_grad():
-                Ws = [_folded_weight(getattr(self, "lin" + str(l))) for l in range(self.num_layers - 1)]
+                fc = self._fold_cache or {}      # this forward's folds (made with grad enabled): reuse their values
+                Ws = []
+                for l in range(self.num_layers - 1):
+                    lin = getattr(self, "lin" + str(l))
+                    w = fc.get(id(lin))
+                    Ws.append(w.detach() if w is not None else _folded_weight(lin))
                 bs = [getattr(self, "lin" + str(l)).bias for l in range(self.num_layers - 1)]
                 if self._packed is None or self._packed.bufs[0][0].device != Ws[0].device or \
                         self._packed.has_bf16 != bool(self.bf16_coarse_search):
@@ -323,6 +342,8 @@ class IDRNetwork(nn.Module):
         self.implicit_network._fold_cache = cache
         self.rendering_network._fold_cache = cache
         try:
+            if self.training:
+                _fold_all((self.implicit_network, self.rendering_network), cache)
             return self._forward(input)
         finally:
             self.implicit_network._fold_cache = None
@@ -429,6 +450,7 @@ class IDRNetwork(nn.Module):
         self.implicit_network._fold_cache = cache
         self.rendering_network._fold_cache = cache
         try:
+            _fold_all((self.implicit_network, self.rendering_network), cache)
             uv, pose, intrinsics = input["uv"], input["pose"], input["intrinsics"]
             object_mask = input["object_mask"].reshape(-1)
             ray_dirs, cam_loc = rend_util.get_camera_params(uv, pose, intrinsics)

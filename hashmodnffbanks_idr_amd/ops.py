@@ -888,6 +888,56 @@ def sine(x, w0):
     return _Sine.apply(x, float(w0))
 
 
+class _WeightNormFold(torch.autograd.Function):
+    """W_l = g_l * v_l / ||v_l||_row for a LIST of weight-normed layers: one launch forward, one backward
+    (torch._weight_norm is one launch per layer and pass)."""
+
+    @staticmethod
+    def forward(ctx, *vg):
+        L = len(vg) // 2
+        vs = [t.contiguous() for t in vg[:L]]
+        gs = [t.contiguous() for t in vg[L:]]
+        ws = [torch.empty_like(v) for v in vs]
+        norms = [torch.empty(v.shape[0], dtype=torch.float32, device=v.device) for v in vs]
+        tab = (_lib.WnLayer * L)()
+        for i in range(L):
+            tab[i].v, tab[i].g, tab[i].w, tab[i].norm = vs[i].data_ptr(), gs[i].data_ptr(), ws[i].data_ptr(), norms[i].data_ptr()
+            tab[i].rows, tab[i].cols = vs[i].shape[0], vs[i].shape[1]
+        check(lib().hm_weight_norm_multi(0, L, C.cast(tab, C.c_void_p), stream_ptr(vs[0])))
+        ctx.L = L
+        ctx.save_for_backward(*vs, *gs, *norms)
+        return tuple(ws)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *gws):
+        L = ctx.L
+        sv = ctx.saved_tensors
+        vs, gs, norms = sv[:L], sv[L:2 * L], sv[2 * L:]
+        idx = [i for i in range(L) if gws[i] is not None]
+        gv = [None] * L
+        gg = [None] * L
+        if idx:
+            keep = []
+            tab = (_lib.WnLayer * len(idx))()
+            for k, i in enumerate(idx):
+                gw = gws[i].contiguous()
+                keep.append(gw)
+                gv[i] = torch.empty_like(vs[i])
+                gg[i] = torch.empty_like(gs[i])
+                tab[k].v, tab[k].g, tab[k].norm = vs[i].data_ptr(), gs[i].data_ptr(), norms[i].data_ptr()
+                tab[k].grad_w, tab[k].grad_v, tab[k].grad_g = gw.data_ptr(), gv[i].data_ptr(), gg[i].data_ptr()
+                tab[k].rows, tab[k].cols = vs[i].shape[0], vs[i].shape[1]
+            check(lib().hm_weight_norm_multi(1, len(idx), C.cast(tab, C.c_void_p), stream_ptr(vs[0])))
+        return (*gv, *gg)
+
+
+def weight_norm_fold(vs, gs):
+    """[g * v / ||v||_row for (v, g) in zip(vs, gs)] (g of shape [rows, 1] or [rows]) - differentiable once."""
+    require_gpu(*vs)
+    return list(_WeightNormFold.apply(*vs, *[g.reshape(-1) for g in gs]))
+
+
 def _rownorm_call(order, y, g, gg, eps):
     out0 = torch.empty_like(y)
     out1 = torch.empty_like(y) if order == 2 else None

@@ -382,6 +382,22 @@ HM_API int hm_softplus(int order, const float *z, const float *gy, const float *
  *              width W = 2 dim + 2 n_freq dim:
  *                order 0: out0 [n, W] = row;   order 1: out0 [n, dim] = (d row / d c)^T g  (g [n, W]);
  *                order 2 (given gg [n, dim] contiguous): out0 [n, W] = d(gg . order1)/d g,  out1 [n, dim] = d(gg . order1)/d c */
+/*   hm_weight_norm_multi  W = g * v / ||v||_row (nn.utils.weight_norm with dim = 0, as every Linear of the SDF and
+ *              rendering networks is wrapped, implicit_differentiable_renderer.py:95-97,205-206) for SEVERAL layers in
+ *              one launch (backward == 0: w and norm are written) and its backward (backward != 0: grad_v, grad_g from
+ *              grad_w and the stored norm); arithmetic of ATen's weight_norm first-dim kernels.  `layers` is a HOST array. */
+typedef struct hm_wn_layer {
+    const float *v;        /* [rows, cols] */
+    const float *g;        /* [rows]       */
+    float *w;              /* [rows, cols] forward output                  */
+    float *norm;           /* [rows]       forward output / backward input */
+    const float *grad_w;   /* [rows, cols] backward input                  */
+    float *grad_v;         /* [rows, cols] backward output                 */
+    float *grad_g;         /* [rows]       backward output                 */
+    int32_t rows, cols;
+} hm_wn_layer;
+HM_API int hm_weight_norm_multi(int backward, int n_layers, const hm_wn_layer *layers, void *stream);
+
 /*   hm_rownorm  (y - mean) / sqrt(var + eps) per row of a contiguous [rows, width] tensor, biased variance - the
  *              nn.InstanceNorm1d call of StyleAttention on a 2-D tensor (style_Attention/styleMod.py:41-43):
  *                order 0: out0 = normalised rows;  order 1: out0 = its backward applied to g;

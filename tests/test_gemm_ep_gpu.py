@@ -59,3 +59,25 @@ def test_gemm_epilogues(M, N, K):
     wt = w.t().contiguous()                                     # [K, N]
     c, o = ops.gemm_ep(a, wt, None, False, False, ops.EPI_S1MUL, BETA, THR, z=z)
     _close(o, (a64 @ wt.double()) * s1, "s1mul NN")
+
+
+def test_weight_norm_fold_multi_matches_torch():
+    """ops.weight_norm_fold: W = g v / ||v|| for a list of layers in one launch and its backward in one launch, against
+    torch._weight_norm per layer (what nn.utils.weight_norm runs, implicit_differentiable_renderer.py:95-97)"""
+    from hashmodnffbanks_idr_amd import ops
+    g0 = torch.Generator(device="cpu").manual_seed(0)
+    shapes = [(512, 67), (512, 512), (445, 512), (512, 512), (257, 512), (3, 512), (1, 7)]
+    vs = [torch.randn(s, generator=g0).cuda().requires_grad_(True) for s in shapes]
+    gs = [(torch.rand((s[0], 1), generator=g0) + 0.5).cuda().requires_grad_(True) for s in shapes]
+    ms = [torch.randn(s, generator=g0).cuda() for s in shapes]
+    ws = ops.weight_norm_fold(vs, gs)
+    sum((w * m).sum() for w, m in zip(ws, ms)).backward()
+    got = [(w.detach(), v.grad.clone(), g.grad.clone()) for w, v, g in zip(ws, vs, gs)]
+    for v, g in zip(vs, gs):
+        v.grad = g.grad = None
+    ref_w = [torch._weight_norm(v, g, 0) for v, g in zip(vs, gs)]
+    sum((w * m).sum() for w, m in zip(ref_w, ms)).backward()
+    for (w, gv, gg), rw, v, g in zip(got, ref_w, vs, gs):
+        assert gg.shape == g.grad.shape
+        for a, b in ((w, rw.detach()), (gv, v.grad), (gg, g.grad)):
+            assert (a - b).abs().max().item() <= 2e-6 * max(b.abs().max().item(), 1e-6)

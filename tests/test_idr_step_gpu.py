@@ -120,6 +120,7 @@ def test_idr_training_steps(golden, merge, cfg, n_steps):
             for k in ("loss", "eikonal_loss", "mask_loss"):
                 ref = float(g[f"s{step}:{k}"])
                 assert abs(lo[k].item() - ref) <= 0.03 * abs(ref) + 1e-4, (step, k, lo[k].item(), ref)
+        before = {n: p.detach().clone() for n, p in model.named_parameters()} if step == 0 else None
         opt.step()
         if step == 0:
             # parameters after one Adam step (lr 1e-4): sampled entries, allow a handful of sign flips
@@ -133,9 +134,16 @@ def test_idr_training_steps(golden, merge, cfg, n_steps):
                 got = p.detach().cpu().numpy().reshape(-1)[idx]
                 bad = np.abs(got - ref) > 2e-6 + 1e-5 * np.abs(ref)
                 worst = max(worst, float(bad.mean()))
-                # (entries whose clipped gradient is of the order of Adam's eps = 1e-8 move by lr * g / (|g| + eps):
-                #  a relative gradient error of 1e-4 there shifts the update by a few 1e-6 - seen on lin8.bias at C2)
-                assert bad.mean() <= (0.10 if mism == 0 else 0.25), (name, bad.sum(), np.abs(got - ref).max())
+                # Adam's first update is lr * g / (|g| + 1e-8).  Entries whose reference update is a full +-lr have
+                # |g| >> eps and must agree firmly; entries whose clipped gradient is of the order of eps move by less,
+                # and a relative gradient error of 1e-4 there shifts the update by a few 1e-6 (seen on lin8.bias at
+                # C2, where every launch-order or rounding change moves one or two of the 64 sampled entries): those
+                # are only bounded by the size of one update
+                upd_ref = np.abs(ref - before[name].cpu().numpy().reshape(-1)[idx])
+                firm = upd_ref >= 0.9e-4
+                if firm.any():
+                    assert bad[firm].mean() <= (0.05 if mism == 0 else 0.25), (name, bad[firm].sum(), firm.sum())
+                assert bad.mean() <= (0.20 if mism == 0 else 0.30), (name, bad.sum(), np.abs(got - ref).max())
                 assert np.abs(got - ref).max() <= 2.5e-4, name
             print(f"    parameters after one Adam step: worst fraction of sampled entries off by a sign flip {worst:.3f}")
 
