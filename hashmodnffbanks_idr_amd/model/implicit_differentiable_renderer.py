@@ -249,7 +249,8 @@ class ImplicitNetwork(nn.Module):
             if e is x:
                 g = g_e
             else:
-                (g,) = torch.autograd.grad(e, x, g_e, create_graph=True, retain_graph=True)
+                with ops.input_grad_only():
+                    (g,) = torch.autograd.grad(e, x, g_e, create_graph=True, retain_graph=True)
             return out, g.unsqueeze(1)
         out = self.forward(x)
         y = out[:, :1]

@@ -393,6 +393,23 @@ def gemm_ep(a, b, bias, trans_a, trans_b, mode, beta, thr, scale=1.0, z=None, g=
     return outs
 
 
+_INPUT_GRAD_ONLY = [False]
+
+
+class input_grad_only:
+    """`with ops.input_grad_only(): torch.autograd.grad(e, x, ..., create_graph=True)` - the caller asks for the gradient
+    w.r.t. the POINTS only.  A custom Function cannot see which of its inputs were asked for (needs_input_grad only says
+    which require grad), so without this hint every Linear of an embedder also forms its weight / bias gradient in that
+    pass (a split-K GEMM, its zeroing launch and a column sum each) just to have it thrown away."""
+
+    def __enter__(self):
+        self.prev = _INPUT_GRAD_ONLY[0]
+        _INPUT_GRAD_ONLY[0] = True
+
+    def __exit__(self, *exc):
+        _INPUT_GRAD_ONLY[0] = self.prev
+
+
 class _MatMul(torch.autograd.Function):
     """C = op(A) @ op(B) + bias.  backward is expressed with the same op, so autograd can
     differentiate it again (ImplicitNetwork.gradient uses create_graph=True)."""
@@ -402,6 +419,7 @@ class _MatMul(torch.autograd.Function):
         ctx.ta, ctx.tb = trans_a, trans_b
         ctx.save_for_backward(a, b)
         ctx.has_bias = bias is not None
+        ctx.is_param = tuple(isinstance(t, torch.nn.Parameter) for t in (a, b, bias))
         return gemm(a, b, bias, trans_a, trans_b)
 
     @staticmethod
@@ -409,12 +427,14 @@ class _MatMul(torch.autograd.Function):
         a, b = ctx.saved_tensors
         ta, tb = ctx.ta, ctx.tb
         da = db = dbias = None
-        if ctx.needs_input_grad[0]:
+        # (parameters are leaves: they cannot lie on a path to the points)
+        skip = ctx.is_param if (_INPUT_GRAD_ONLY[0] and torch.is_grad_enabled()) else (False, False, False)
+        if ctx.needs_input_grad[0] and not skip[0]:
             # dA' = dC B'^T ; stored layout follows ta
             da = matmul(b, dc, None, tb, True) if ta else matmul(dc, b, None, False, not tb)
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and not skip[1]:
             db = matmul(dc, a, None, True, ta) if tb else matmul(a, dc, None, not ta, False)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if ctx.has_bias and ctx.needs_input_grad[2] and not skip[2]:
             dbias = colsum(dc)
         return da, db, dbias, None, None
 
