@@ -25,8 +25,13 @@
 namespace {
 
 constexpr int kNT = 256;   // threads per workgroup
-constexpr int kLP = 8;     // lanes per point: each lane owns W/8 of every layer's outputs (W = 56 / 72)
-constexpr int kPP = kNT / kLP;   // points per workgroup (32)
+// LP = lanes per point (template value): each lane owns ceil(W / LP) of every layer's outputs (W = 56 / 72).
+//   LP = 8  (32 points per workgroup): big launches, throughput
+//   LP = 32 (8 points per workgroup): the tracer's march / secant rounds (<= 8192 live points).  A call is one serial
+//           chain per point - ~14 matrix-vector products whose weight rows are loaded through the L1 - and took ~92 us
+//           whatever its size; four times fewer rows per lane cut that chain, and every row is still one lane's k-ordered
+//           fma chain, so the values do not depend on LP.
+constexpr int kSmallCount = 8192;
 
 struct NffbArgs {   // by value
     const float *trunk_w[HM_MAX_LEVELS];   // ff_lin0 [W,3], ff_lin1.. [W,W]
@@ -55,13 +60,14 @@ __device__ __forceinline__ void nffb_corner(float x, int32_t res, int bit, uint3
 // row; the barrier-separated read-back gives every lane of the point the whole vector again.
 // SINE: the Sine activation sin(w0 .) is applied by the lane that owns the row, BEFORE the exchange (applied after the
 // read-back every one of the 8 lanes would evaluate all W sines again).
-template <int W, int K, bool SINE>
+template <int W, int K, bool SINE, int LP>
 __device__ __forceinline__ void matvec_rows(const float *__restrict__ Wm, const float *__restrict__ b,
                                             const float (&v)[K], int sub, float *prow, float w0 = 0.0f) {
-    constexpr int R = W / kLP;
+    constexpr int R = (W + LP - 1) / LP;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int jrow = sub + kLP * r;
+        const int jrow = sub + LP * r;
+        if (W % LP != 0 && jrow >= W) break;      // (LP = 32: the last slice of rows is partial)
         const float *row = Wm + jrow * K;
         float acc;
         if (K % 4 == 0) {
@@ -89,18 +95,21 @@ __device__ __forceinline__ void matvec_rows(const float *__restrict__ Wm, const 
     }
 }
 
-template <int FRAC, int LV, bool STYLE>
+template <int FRAC, int LV, bool STYLE, int LP>
 __global__ __launch_bounds__(kNT) void nffb_fwd_kernel(HmLevels lv, NffbArgs a, const float *__restrict__ x, int64_t n,
                                                        const float *__restrict__ table,
                                                        const float *__restrict__ Bf, float *__restrict__ out,
-                                                       int64_t out_stride, const int32_t *__restrict__ n_dev) {
+                                                       int64_t out_stride, const int32_t *__restrict__ n_dev,
+                                                       int64_t run_min, int64_t run_max) {
     constexpr int W = 8 + 8 * LV;
-    constexpr int R = W / kLP;
+    constexpr int kLP = LP, kPP = kNT / LP;
+    constexpr int R = (W + kLP - 1) / kLP;
     constexpr int NG = 4 * (LV - 2);   // grid values that are ever consumed: chunks 0 .. LV-3
     constexpr int WP = W + 4;          // padded LDS row (keeps 16-byte alignment, staggers the banks of the 32 rows)
     __shared__ __align__(16) float T[kPP * WP];    // per point: the vector being exchanged between its 8 lanes
     __shared__ float G[kPP * NG];                  // per point: the consumed part of the grid row
     if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));
+    if (n < run_min || n > run_max) return;      // the other lanes-per-point variant owns this batch size
     const int tid = threadIdx.x;
     const int pt = tid / kLP, sub = tid % kLP;
     float *prow = T + pt * WP;
@@ -156,7 +165,7 @@ __global__ __launch_bounds__(kNT) void nffb_fwd_kernel(HmLevels lv, NffbArgs a, 
         float feat[R];     // this lane's rows of the feature accumulator
 #pragma unroll
         for (int r = 0; r < R; ++r) feat[r] = 0.0f;
-        matvec_rows<W, 3, true>(a.trunk_w[0], a.trunk_b[0], xn, sub, prow, a.w0);
+        matvec_rows<W, 3, true, LP>(a.trunk_w[0], a.trunk_b[0], xn, sub, prow, a.w0);
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < W; ++k) xv[k] = prow[k];
@@ -164,7 +173,7 @@ __global__ __launch_bounds__(kNT) void nffb_fwd_kernel(HmLevels lv, NffbArgs a, 
 #pragma unroll 1
         for (int layer = 1; layer < LV - 1; ++layer) {
             __syncthreads();
-            matvec_rows<W, W, true>(a.trunk_w[layer], a.trunk_b[layer], xv, sub, prow, a.w0);
+            matvec_rows<W, W, true, LP>(a.trunk_w[layer], a.trunk_b[layer], xv, sub, prow, a.w0);
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < W; ++k) xv[k] = prow[k];
@@ -174,6 +183,7 @@ __global__ __launch_bounds__(kNT) void nffb_fwd_kernel(HmLevels lv, NffbArgs a, 
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int k = sub + kLP * r;
+                if (W % kLP != 0 && k >= W) break;
                 const float c = grow[4 * (layer - 1) + (k & 3)];
                 float v = c;
                 if (k >= 8) {
@@ -190,7 +200,7 @@ __global__ __launch_bounds__(kNT) void nffb_fwd_kernel(HmLevels lv, NffbArgs a, 
                 // StyleAttention: linear_transform(e) * softmax over a size-1 dim (== 1), then the per-row
                 // InstanceNorm over the W features (biased variance), styleMod.py:30-43
                 __syncthreads();
-                matvec_rows<W, W, false>(a.style_w, a.style_b, e, sub, prow);
+                matvec_rows<W, W, false, LP>(a.style_w, a.style_b, e, sub, prow);
                 __syncthreads();
                 float mean = 0.0f;
 #pragma unroll
@@ -213,16 +223,18 @@ __global__ __launch_bounds__(kNT) void nffb_fwd_kernel(HmLevels lv, NffbArgs a, 
 #pragma unroll
             for (int k = 0; k < W; ++k) e[k] = __fadd_rn(e[k], xv[k]);
             __syncthreads();
-            matvec_rows<W, W, false>(a.out_w, a.out_b, e, sub, prow);
+            matvec_rows<W, W, false, LP>(a.out_w, a.out_b, e, sub, prow);
             // (each lane reads back only the rows it wrote: no barrier needed)
 #pragma unroll
-            for (int r = 0; r < R; ++r) feat[r] = __fadd_rn(feat[r], prow[sub + kLP * r]);
+            for (int r = 0; r < R; ++r)
+                if (W % kLP == 0 || sub + kLP * r < W) feat[r] = __fadd_rn(feat[r], prow[sub + kLP * r]);
         }
         if (live) {
             float *o = out + i * out_stride;
             if (sub < 3) o[sub] = sub == 0 ? u0 : (sub == 1 ? u1 : u2);
 #pragma unroll
-            for (int r = 0; r < R; ++r) o[3 + sub + kLP * r] = __fdiv_rn(feat[r], (float)LV);
+            for (int r = 0; r < R; ++r)
+                if (W % kLP == 0 || sub + kLP * r < W) o[3 + sub + kLP * r] = __fdiv_rn(feat[r], (float)LV);
         }
     }
 }
@@ -230,18 +242,31 @@ __global__ __launch_bounds__(kNT) void nffb_fwd_kernel(HmLevels lv, NffbArgs a, 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 template <int FRAC, int LV, bool STYLE>
-int launch_nffb1(unsigned grid, hipStream_t st, const HmLevels &lv, const NffbArgs &a, const float *x, int64_t n,
-                 const float *table, const float *Bf, float *out, int64_t out_stride, const int32_t *n_dev) {
-    hipLaunchKernelGGL((nffb_fwd_kernel<FRAC, LV, STYLE>), dim3(grid), dim3(kNT), 0, st, lv, a, x, n, table, Bf, out,
-                       out_stride, n_dev);
+int launch_nffb1(hipStream_t st, const HmLevels &lv, const NffbArgs &a, const float *x, int64_t n, const float *table,
+                 const float *Bf, float *out, int64_t out_stride, const int32_t *n_dev) {
+    // with a device-side count the host cannot know the batch size: both variants are enqueued and each returns at
+    // once unless the live count falls in its range (like the fused SDF kernels)
+    const bool small = n <= kSmallCount, big = n_dev ? n > kSmallCount : !small;
+    const int64_t kBig = (int64_t)1 << 62;
+    if (small || n_dev) {
+        const int64_t cap = n < kSmallCount ? n : kSmallCount;
+        const int64_t blocks = (cap + kNT / 32 - 1) / (kNT / 32);
+        hipLaunchKernelGGL((nffb_fwd_kernel<FRAC, LV, STYLE, 32>), dim3((unsigned)blocks), dim3(kNT), 0, st, lv, a, x, n, table,
+                           Bf, out, out_stride, n_dev, (int64_t)0, (int64_t)kSmallCount);
+    }
+    if (big) {
+        const int64_t blocks = (n + kNT / 8 - 1) / (kNT / 8);
+        hipLaunchKernelGGL((nffb_fwd_kernel<FRAC, LV, STYLE, 8>), dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(kNT),
+                           0, st, lv, a, x, n, table, Bf, out, out_stride, n_dev, (int64_t)kSmallCount + 1, kBig);
+    }
     return HM_OK;
 }
 
 template <int FRAC, int LV>
-int launch_nffb(bool style, unsigned grid, hipStream_t st, const HmLevels &lv, const NffbArgs &a, const float *x,
-                int64_t n, const float *table, const float *Bf, float *out, int64_t out_stride, const int32_t *n_dev) {
-    return style ? launch_nffb1<FRAC, LV, true>(grid, st, lv, a, x, n, table, Bf, out, out_stride, n_dev)
-                 : launch_nffb1<FRAC, LV, false>(grid, st, lv, a, x, n, table, Bf, out, out_stride, n_dev);
+int launch_nffb(bool style, hipStream_t st, const HmLevels &lv, const NffbArgs &a, const float *x, int64_t n,
+                const float *table, const float *Bf, float *out, int64_t out_stride, const int32_t *n_dev) {
+    return style ? launch_nffb1<FRAC, LV, true>(st, lv, a, x, n, table, Bf, out, out_stride, n_dev)
+                 : launch_nffb1<FRAC, LV, false>(st, lv, a, x, n, table, Bf, out, out_stride, n_dev);
 }
 
 }  // namespace
@@ -273,13 +298,11 @@ int hm_nffb_fwd(const hm_grid_desc *desc, const hm_nffb_desc *nf, const float *x
     HM_CHECK_ARG((nf->style_w == nullptr) == (nf->style_b == nullptr), "hm_nffb_fwd: style weight / bias must come together");
     a.bound = nf->bound; a.w0 = nf->w0; a.style_eps = nf->style_eps;
     const bool style = nf->style_w != nullptr;
-    const int64_t blocks = (n + kPP - 1) / kPP;
-    const unsigned grid = (unsigned)(blocks < 4096 ? blocks : 4096);
     hipStream_t st = as_stream(stream);
     int rc;
 #define HM_NFFB(FR)                                                                                                    \
-    rc = (lv.L == 6) ? launch_nffb<FR, 6>(style, grid, st, lv, a, x, n, table, B_fourier, out, out_stride, n_dev)      \
-                     : launch_nffb<FR, 8>(style, grid, st, lv, a, x, n, table, B_fourier, out, out_stride, n_dev)
+    rc = (lv.L == 6) ? launch_nffb<FR, 6>(style, st, lv, a, x, n, table, B_fourier, out, out_stride, n_dev)            \
+                     : launch_nffb<FR, 8>(style, st, lv, a, x, n, table, B_fourier, out, out_stride, n_dev)
     if (frac_mode == HM_FRAC_REFERENCE) { HM_NFFB(HM_FRAC_REFERENCE); } else { HM_NFFB(HM_FRAC_TRILINEAR); }
 #undef HM_NFFB
     if (rc != HM_OK) return rc;

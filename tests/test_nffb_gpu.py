@@ -60,6 +60,12 @@ def test_fused_embedder_forward(golden, tag, et, L):
     np.testing.assert_allclose(yf.cpu().numpy(), ya.cpu().numpy(), rtol=1e-4, atol=2e-5)
     with torch.no_grad():
         assert emb(xr[:1]).shape == (1, 3 + 8 + 8 * L) and emb(xr[:0]).shape[0] == 0
+        # big launches (> 8192 points: 8 lanes per point) and small ones (32 lanes per point) give the same bits: every
+        # output row is one lane's k-ordered fma chain either way
+        xb = (torch.rand(20000 + 11, 3, device="cuda") * 2.2 - 1.1)
+        yb = emb(xb)
+        ys = torch.cat([emb(xb[i:i + 4000]) for i in range(0, xb.shape[0], 4000)], 0)
+        assert torch.equal(yb, ys)
 
 
 @pytest.mark.parametrize("tag,et", [("ffb", "FFB"), ("stylemod", "StyleModNFFB")])
