@@ -13,8 +13,8 @@
 // (56 / 72 columns, a sin or a per-row normalisation after every product), and on gfx950 the fp32 MFMA rate EQUALS
 // the fp32 VALU rate (157 TFLOP/s both), so the exact-fp32 products run as k-ordered fma chains on the VALU.  Lane s
 // of a point owns rows s, s+8, ... (7 or 9 of them) of every product; its weight rows arrive as 16-byte vector loads
-// from the CU's L1 (the matrices are 12 - 21 KB), the input vector sits replicated in the 8 lanes' registers
-// (static indices), and the outputs are exchanged through a per-point LDS row.  Splitting a point over 8 lanes is
+// from the CU's L1 (the matrices are 12 - 21 KB), the input vector sits replicated in the point's lanes' registers
+// (static indices), and the outputs are exchanged through a per-point LDS row.  Splitting a point over 8 (or 32) lanes is
 // what makes the ~50 small calls of a ray search cheap: the first version (one thread per point, weights as scalar
 // operands) had a 120 us serial chain per call however few points it held; here the chain is 8x shorter and a
 // 4096-point round fills every CU.  -ffp-contract=off file: same dot-product order as torch's sgemm up to blocking.
@@ -59,7 +59,7 @@ __device__ __forceinline__ void nffb_corner(float x, int32_t res, int bit, uint3
 // read as 16-byte vector loads: the matrices are 12 - 21 KB and stay in the CU's L1) and leaves them in the point's LDS
 // row; the barrier-separated read-back gives every lane of the point the whole vector again.
 // SINE: the Sine activation sin(w0 .) is applied by the lane that owns the row, BEFORE the exchange (applied after the
-// read-back every one of the 8 lanes would evaluate all W sines again).
+// read-back every one of the point's lanes would evaluate all W sines again).
 template <int W, int K, bool SINE, int LP>
 __device__ __forceinline__ void matvec_rows(const float *__restrict__ Wm, const float *__restrict__ b,
                                             const float (&v)[K], int sub, float *prow, float w0 = 0.0f) {
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(kNT) void nffb_fwd_kernel(HmLevels lv, NffbArgs a, 
     constexpr int R = (W + kLP - 1) / kLP;
     constexpr int NG = 4 * (LV - 2);   // grid values that are ever consumed: chunks 0 .. LV-3
     constexpr int WP = W + 4;          // padded LDS row (keeps 16-byte alignment, staggers the banks of the 32 rows)
-    __shared__ __align__(16) float T[kPP * WP];    // per point: the vector being exchanged between its 8 lanes
+    __shared__ __align__(16) float T[kPP * WP];    // per point: the vector being exchanged between its lanes
     __shared__ float G[kPP * NG];                  // per point: the consumed part of the grid row
     if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));
     if (n < run_min || n > run_max) return;      // the other lanes-per-point variant owns this batch size
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(kNT) void nffb_fwd_kernel(HmLevels lv, NffbArgs a, 
         const float u0 = __fdiv_rn(__fadd_rn(p0, a.bound), two_b), u1 = __fdiv_rn(__fadd_rn(p1, a.bound), two_b),
                     u2 = __fdiv_rn(__fadd_rn(p2, a.bound), two_b);
         __syncthreads();   // the previous tile has left T / G
-        // ---- grid row without its 3 pass-through columns: [sin(L) | cos(L) | level features]; the 8 lanes of a
+        // ---- grid row without its 3 pass-through columns: [sin(L) | cos(L) | level features]; the lanes of a
         //      point share the 2L sin/cos channels and the (<= L-4) consumed levels ------------------------------
         {
             const float two_pi = 6.283185307179586f;

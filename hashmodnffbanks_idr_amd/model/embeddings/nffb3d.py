@@ -11,9 +11,10 @@ Data flow (registry settings: PositionalEncodingNET, SIREN, has_out=False):
 Two routes:
   * no gradient needed (ray tracing, eval, plots): ONE fused kernel for the whole embedder - grid gather, positional
     encodings, SIREN trunk, StyleAttention normalisation, shared out_layer, mean over levels (csrc/hm_nffb.hip via
-    ops.nffb_fwd; one thread per point, weights as scalar operands);
+    ops.nffb_fwd; 8 or 32 lanes per point, the weight rows read through the L1);
   * gradient needed: hash-grid gather on the HIP encoder kernels, every Linear on the HIP fp32 MFMA GEMM (ops.linear,
-    differentiable to any order); sin/cos/normalisation are elementwise torch expressions.
+    differentiable to any order); the SIREN activation, the positional encodings and StyleAttention's normalisation are
+    fused ops with one kernel per pass (ops.sine / ops.posenc / ops.rownorm: forward, backward, double backward).
 """
 import torch
 import torch.nn as nn
