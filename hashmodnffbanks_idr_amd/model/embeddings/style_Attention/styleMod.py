@@ -28,7 +28,8 @@ class StyleAttention(nn.Module):
         content_features = content.view(-1, self.d_in)
         style_features = style.view(-1, self.feature_vector_size)
         modulated = ops.linear(style_features, self.linear_transform.weight, self.linear_transform.bias)
-        if modulated.is_cuda and modulated.requires_grad and torch.is_grad_enabled() and self.fused_norm:
+        if (modulated.is_cuda and modulated.requires_grad and torch.is_grad_enabled() and self.fused_norm
+                and modulated.shape[1] <= 128):
             # grad path: the softmax over a size-1 dimension is exactly 1.0 and its backward exactly 0, so `weighted`
             # IS `modulated` and the attention Linear (and `content`) receive exact zeros - produced here by a zero-weight
             # term instead of the softmax / K=3 linear chain and its double backward; the row normalisation and its
