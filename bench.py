@@ -50,7 +50,7 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s ach
 MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
 SDF_MAC_PER_POINT = 1966592  # SURVEY.md 8a row A9 (independent of the embedding width)
 RAYS_PER_GPU = 2048
-LAZY_SAMPLER_HEAD = 16   # RayTracing.sampler_head of the product (model/ray_tracing.py); legs other than "lazy" use 0
+LAZY_SAMPLER_HEAD = int(os.environ.get("HM_LAZY_HEAD", "16"))   # RayTracing.sampler_head of the product (model/ray_tracing.py); legs other than "lazy" use 0
 CFG = "C2"          # BASELINE.json configs[1]; `--gpus 8` defaults to configs[3] ("C4", T=2^22)
 
 
