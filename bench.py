@@ -2,15 +2,18 @@
 """bench.py - rays/sec fwd+bwd (hash + SDF MLP) and hash-gather HBM GB/s on MI355X.
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W   -> ONE JSON line on rank 0.
-For N>1 it is launched by torch.distributed.run, one rank per GPU (RCCL over xGMI).
+For N>1 it is launched by torch.distributed.run, one rank per GPU (RCCL over xGMI); started WITHOUT that launcher
+(`python bench.py --gpus N`, no WORLD_SIZE in the environment) it starts the N ranks itself as a child
+`python -m torch.distributed.run ...` before anything touches the GPU and relays rank 0's line.
 
 A "step" = one training iteration of the hot path on one batch of synthetic uniform-sphere rays
 (SURVEY.md section 8d), in the reference runner's order (idr_train.py:294-308):
 IDRNetwork.forward (sphere tracing with the fused SDF kernel, grad-enabled SDF / rendering MLPs,
 gradient() with create_graph) + IDRLoss + backward + [gradient all-reduce] + clip_grad_norm_ + Adam.
 Workload = BASELINE.json configs[1]: MultiResHash L=16 T=2^19 F=2, 2048 rays PER GPU (weak
-scaling), fp32, geometric-init weights seed 0, object_mask all true, rgb_gt = 0
-(`--gpus 8`: configs[3], T=2^22, 16 384 rays over the 8 GPUs).
+scaling), fp32, geometric-init weights seed 0, object_mask all true, rgb_gt = 0 - the SAME table for every N, so the
+1 -> 8 curve compares like with like; BASELINE configs[3] (T=2^22; 16 384 rays over 8 GPUs = the same 2048 rays per
+GPU) is `--cfg C4` and is reported beside the headline as `config4_leg` at every N.
 
 Two legs are timed, each over exactly K steps:
   value / ms_per_step   the section-8(d) workload: the weights STAY at the geometric initialisation (the whole
@@ -51,7 +54,7 @@ MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector p
 SDF_MAC_PER_POINT = 1966592  # SURVEY.md 8a row A9 (independent of the embedding width)
 RAYS_PER_GPU = 2048
 LAZY_SAMPLER_HEAD = int(os.environ.get("HM_LAZY_HEAD", "16"))   # RayTracing.sampler_head of the product (model/ray_tracing.py); legs other than "lazy" use 0
-CFG = "C2"          # BASELINE.json configs[1]; `--gpus 8` defaults to configs[3] ("C4", T=2^22)
+CFG = "C2"          # BASELINE.json configs[1] at EVERY --gpus N (one table for the whole scaling curve); configs[3] = --cfg C4
 
 
 class Conf(dict):
@@ -394,6 +397,43 @@ def _build(cfg, device, lr):
     return model
 
 
+def _make_reducer(model, world, no_graph):
+    """gradient exchange of a data-parallel leg: static steps use parallel.StaticGradExchange (hash-table gradients as
+    (row, value) lists, ~1 MB per rank instead of 40 / 224 MB, device work captured into the step's graphs, two
+    collectives per step); HM_DP_SPARSE=0 or --no-graph: dense all-reduce of everything (parallel.GradAllReducer)"""
+    from hashmodnffbanks_idr_amd import parallel
+    if not (world > 1 or os.environ.get("HM_DIST_FORCE") == "1"):    # (HM_DIST_FORCE: single-rank RCCL rehearsal)
+        return None
+    if no_graph or os.environ.get("HM_DP_SPARSE", "1") == "0":
+        return parallel.GradAllReducer(model.parameters())
+    tables = []
+    for net in (model.implicit_network, model.rendering_network):
+        emb = getattr(getattr(net, "embed_model", None), "embedder_obj", None)
+        emb = getattr(emb, "grid_enc", emb)          # filter-bank embedders own a hash grid too
+        if emb is not None and hasattr(emb, "grad_collector") and emb.frac_mode == "reference":
+            tables.append(emb)
+    return parallel.StaticGradExchange(model.parameters(), tables=tables)
+
+
+def _spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD torch.distributed.run (nothing has
+    touched the GPU yet: counting devices does not initialise it), relay its output, exit with its code."""
+    import socket
+    import subprocess
+    env = os.environ.copy()
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus and "HM_DIST_BACKEND" not in env:
+        # fewer devices than ranks (rehearsal on a one-GPU box): RCCL refuses two ranks per device, gloo does not
+        env["HM_DIST_BACKEND"] = "gloo"
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    return subprocess.run(cmd, env=env).returncode
+
+
 def _side_leg(cfg, device, bf16, steps=6, warmup=3, sampler_head=0):
     """short fixed-weights leg of another BASELINE configuration on rank 0 (reported beside the headline)"""
     import types
@@ -493,10 +533,12 @@ def main():
     ap.add_argument("--only", choices=["gather", "gather_bwd", "mlp", "mlp_bf16", "gemm", "gather_calib"], default=None,
                     help="profiling helper: run just one kernel section on cuda:0 and print its object")
     ap.add_argument("--cfg", default=None,
-                    help="hash-grid config (tests/golden/params.py): default C2 = BASELINE configs[1]; C4 = configs[3] "
-                         "is the default for --gpus 8")
+                    help="hash-grid config (tests/golden/params.py): default C2 = BASELINE configs[1] at every --gpus N; "
+                         "C4 = configs[3] (T = 2^22), C3 / C5 = the filter-bank configurations")
     args = ap.parse_args()
-    cfg = args.cfg or os.environ.get("HM_BENCH_CFG") or ("C4" if args.gpus == 8 else CFG)
+    cfg = args.cfg or os.environ.get("HM_BENCH_CFG") or CFG
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ and not args.only:
+        sys.exit(_spawn_ranks(args))
 
     if args.only == "gather_calib":
         # PMC calibration of 8-byte gathers (run under rocprofv3 --pmc ...; see profiles/README.md)
@@ -533,7 +575,7 @@ def main():
     from hashmodnffbanks_idr_amd.model.loss import IDRLoss
 
     rank, world, local_rank = parallel.init_distributed()
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     n_dev = torch.cuda.device_count()
     device = torch.device("cuda", local_rank % max(n_dev, 1))  # (rehearsal: several gloo ranks may share one GPU)
@@ -556,36 +598,44 @@ def main():
         return ClipAdam(model.parameters(), lr=lr, max_norm=1.0)
 
     use_bf16 = (args.bf16 == 1) or (args.bf16 < 0 and cfg == "C5")
+
+    def run_one(cfg_, lr, sampler_head, steps, warmup, bf16):
+        """one timed leg on ALL ranks (it contains collectives when world > 1)"""
+        import types
+        a = types.SimpleNamespace(no_graph=args.no_graph, warmup=warmup, steps=steps, rays=args.rays)
+        model = _build(cfg_, device, lr)
+        model.implicit_network.bf16_coarse_search = bf16
+        model.ray_tracer.sampler_head = sampler_head
+        reducer = _make_reducer(model, world, args.no_graph)
+        torch.manual_seed(100 + rank)  # per-rank eikonal points / step fractions
+        dt, stats, final_loss, mode = _run_leg(a, model, make_opt(model, lr), loss_fn, reducer, inp, gt, world, device, rank)
+        rec = {"value": round(args.rays * world * steps / dt, 1), "unit": "rays/s",
+               "ms_per_step": round(dt / steps * 1e3, 3), "lr": lr, "sampler_head": sampler_head,
+               "sdf_evals_per_step": stats, "final_loss": round(final_loss, 6), "step": mode}
+        if reducer is not None:
+            rec["exchange"] = type(reducer).__name__
+            if hasattr(reducer, "check"):
+                reducer.check()        # (host read after the timed region: no touched row may have missed its payload)
+        return rec, model
+
     legs = {}
     model = None
     for leg, lr, sampler_head in (("fixed", 0.0, 0), ("train", 1.0e-4, 0), ("lazy", 0.0, LAZY_SAMPLER_HEAD)):
         if args.legs not in ("both", leg):
             continue
-        model = _build(cfg, device, lr)
-        model.implicit_network.bf16_coarse_search = use_bf16
-        model.ray_tracer.sampler_head = sampler_head
-        reducer = None
-        if world > 1 or os.environ.get("HM_DIST_FORCE") == "1":   # (HM_DIST_FORCE: single-rank RCCL rehearsal)
-            # hash-table gradients travel as (point, feature-gradient) pairs (parallel.PointGradExchange, ~0.7 MB per
-            # rank instead of 40 / 224 MB dense) in the static graph step; HM_DP_SPARSE=0 or --no-graph: dense all-reduce
-            exchanges = []
-            if not args.no_graph and os.environ.get("HM_DP_SPARSE", "1") != "0":
-                for net in (model.implicit_network, model.rendering_network):
-                    emb = getattr(getattr(net, "embed_model", None), "embedder_obj", None)
-                    emb = getattr(emb, "grid_enc", emb)          # filter-bank embedders own a hash grid too
-                    if emb is not None and hasattr(emb, "grad_collector"):
-                        exchanges.append(parallel.PointGradExchange(emb))
-            reducer = parallel.GradAllReducer(model.parameters(), sparse=exchanges)
-        torch.manual_seed(100 + rank)  # per-rank eikonal points / step fractions
-        dt, stats, final_loss, mode = _run_leg(args, model, make_opt(model, lr), loss_fn, reducer, inp, gt, world,
-                                               device, rank)
-        legs[leg] = {"value": round(args.rays * world * args.steps / dt, 1), "unit": "rays/s",
-                     "ms_per_step": round(dt / args.steps * 1e3, 3), "lr": lr, "sampler_head": sampler_head,
-                     "sdf_evals_per_step": stats, "final_loss": round(final_loss, 6), "step": mode}
+        legs[leg], model = run_one(cfg, lr, sampler_head, args.steps, args.warmup, use_bf16)
         if leg == "fixed":
             head_model = model
     if "fixed" not in legs:
         head_model = model
+    c4_leg = None
+    if not args.no_extras and cfg == "C2" and args.rays == RAYS_PER_GPU:
+        # BASELINE configs[3] (T = 2^22; 16 384 rays over 8 GPUs = these 2048 rays per GPU), short fixed-weights leg at
+        # EVERY N so that its own 1 -> 8 curve exists beside the headline's
+        c4_leg, _m = run_one("C4", 0.0, 0, min(args.steps, 10), 3, False)
+        c4_leg["workload"] = "MultiResHash L=16 T=2^22 F=2 (BASELINE.json configs[3]), 2048 rays per GPU, weights at init"
+        c4_leg["steps"] = min(args.steps, 10)
+        del _m
 
     if rank == 0:
         head = legs.get("fixed") or legs.get("train") or legs["lazy"]
@@ -605,6 +655,10 @@ def main():
                                       if "fixed" in legs else ", lr 1e-4 (surface moves during the timed region)"),
                        "grid_config": cfg, "rays_per_gpu": args.rays, "global_rays": args.rays * world,
                        "parallelism": f"ray-sharded dp{world}" if world > 1 else "single GPU",
+                       "world": world,
+                       "backend": (torch.distributed.get_backend() if torch.distributed.is_initialized() else None),
+                       "ranks_seen": (torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1),
+                       "exchange": head.get("exchange"),
                        "step": head["step"],
                        "sampler": ("all n_steps samples of every unconverged ray are evaluated, as in the reference "
                                    "(ray_tracing.py:189-249)" if head["sampler_head"] == 0 else
@@ -620,7 +674,15 @@ def main():
             # the product default.  Reported beside the headline because SURVEY.md 8(d) characterises the workload by
             # the reference's evaluation count (~123 per ray), which the lazy sampler undercuts.
             line["lazy_sampler_leg"] = legs["lazy"]
-        if not args.no_extras and cfg in NFFB_CONFIGS:
+        if c4_leg is not None:
+            line["config4_leg"] = c4_leg
+        if not args.no_extras and world > 1:
+            # N > 1: the kernel rooflines / CPU baseline are single-GPU measurements and belong to the N = 1 line
+            emb = head_model.implicit_network.embed_model.embedder_obj
+            emb = getattr(emb, "grid_enc", emb)
+            if not (cfg in NFFB_CONFIGS):
+                line["roofline"] = gather_roofline(emb, args.gather_log2n)
+        elif not args.no_extras and cfg in NFFB_CONFIGS:
             line["cpu_baseline"] = None      # (the torch-CPU port covers the hash-grid embedder only)
         elif not args.no_extras:
             emb = head_model.implicit_network.embed_model.embedder_obj

@@ -65,6 +65,11 @@ SIGNATURES = {
     "hm_idr_loss": (_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, C.c_float, C.c_float, C.c_float, _p, _p, _p, _p, _p]),
     "hm_adam_scratch_floats": (_i64, [_p, _int]),
     "hm_adam_step": (_int, [_p, _int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _p, _p]),
+    "hm_encode_bwd_table_tracked": (_int, [_p, _p, _i64, _p, _i64, _p, _int, _p, _p, _p, _i64, _p]),
+    "hm_rows_pack": (_int, [_p, _int, _p, _p, _i64, _p, _p, _p, _p]),
+    "hm_rows_apply": (_int, [_p, _i64, _int, _p, _i64, _i64, _int, C.c_float, _p]),
+    "hm_rows_clear": (_int, [_p, _i64, _int, _p, _i64, _i64, _int, _p, _p]),
+    "hm_multi_copy_f32": (_int, [_p, _int, _p]),
     "hm_gemm_f32_ep": (_int, [_int, _int, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _p]),
     "hm_gemm_f32": (_int, [_int, _int, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _int, _p]),
 }
@@ -87,6 +92,10 @@ class GemmEpilogue(C.Structure):
 class AdamTensor(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
                 ("step", C.c_void_p), ("numel", C.c_int64)]
+
+
+class CopyItem(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("numel", C.c_int64)]
 
 
 class TraceCfg(C.Structure):

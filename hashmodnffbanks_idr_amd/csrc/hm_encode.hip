@@ -572,6 +572,56 @@ __global__ __launch_bounds__(kThreads) void encode_bwd_table_kernel(HmLevels lv,
     for (int f = 0; f < F; ++f) atomicAdd(row + f, __fmul_rn(w, g[f]));
 }
 
+// The same scatter for data-parallel steps (parallel.TouchedRowExchange): besides adding into d_table it lists every
+// table row it touches ONCE - a bit per row is claimed with atomicOr, the lanes of a wave that claimed a new row take
+// consecutive slots of touched_rows with one atomicAdd per wave.  The rank's (row, value) pairs are then read off
+// d_table by hm_rows_pack; nothing is sorted anywhere.
+template <int FRAC>
+__global__ __launch_bounds__(kThreads) void encode_bwd_table_tracked_kernel(HmLevels lv, const float *__restrict__ x,
+                                                                            int64_t n, const float *__restrict__ d_feat,
+                                                                            int64_t d_feat_stride,
+                                                                            float *__restrict__ d_table,
+                                                                            uint32_t *__restrict__ bits,
+                                                                            int32_t *__restrict__ count,
+                                                                            int32_t *__restrict__ rows_out, int64_t cap) {
+    const int L = lv.L, F = lv.F;
+    const int64_t gid = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int c = (int)(gid & 7);
+    const int64_t pl = gid >> 3;
+    const int64_t i = pl / L;
+    const int l = (int)(pl - i * L);
+    bool claimed = false;
+    uint32_t grow = 0u;
+    if (i < n) {
+        uint32_t u[3];
+        float w = 1.0f;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            float wd;
+            voxel_and_weight<FRAC>(x[i * 3 + d], lv.res[l], (c >> d) & 1, u[d], wd);
+            w = __fmul_rn(w, wd);
+        }
+        if (w != 0.0f) {
+            grow = lv.row_off[l] + hm_mod_rows(hm_hash3(u[0], u[1], u[2]), lv.rows[l], lv.magic[l]);
+            const float *g = d_feat + i * d_feat_stride + l * F;
+            float *row = d_table + (uint64_t)grow * F;
+            for (int f = 0; f < F; ++f) atomicAdd(row + f, __fmul_rn(w, g[f]));
+            const uint32_t bit = 1u << (grow & 31u);
+            claimed = (atomicOr(bits + (grow >> 5), bit) & bit) == 0u;
+        }
+    }
+    const uint64_t m = __ballot(claimed);
+    if (m == 0ull) return;
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == (int)__ffsll((long long)m) - 1) base = atomicAdd(count, (int32_t)__popcll(m));
+    base = __shfl(base, (int)__ffsll((long long)m) - 1);
+    if (claimed) {
+        const int64_t slot = (int64_t)base + __popcll(m & ((1ull << lane) - 1ull));
+        if (slot < cap) rows_out[slot] = (int32_t)grow;     // (slot >= cap: reported by hm_rows_pack through `status`)
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // z-ordered table gradient for big launches (F = 2).  Scattering one 4-byte atomic per lane into 64 different rows
 // runs at a sixteenth of the atomic rate (the guide's 0.08 TB/s case): the atomic kernel above needs 8.2 ms for 2^22
@@ -810,6 +860,32 @@ int hm_encode_bwd_table_ws(const hm_grid_desc *desc, const float *x, int64_t n, 
         hipLaunchKernelGGL(encode_bwd_table_zorder_kernel<HM_FRAC_TRILINEAR>, dim3(kSlabs, lv.L), dim3(kBwdThreads), lds, st,
                            lv, xs, reinterpret_cast<const float2 *>(dfs), n, hist + kSlabs, d_table);
     HM_CHECK_LAUNCH("hm_encode_bwd_table_ws");
+    return HM_OK;
+}
+
+int hm_encode_bwd_table_tracked(const hm_grid_desc *desc, const float *x, int64_t n, const float *d_feat,
+                                int64_t d_feat_stride, float *d_table, int frac_mode, uint32_t *touched_bits,
+                                int32_t *touched_count, int32_t *touched_rows, int64_t cap, void *stream) {
+    HM_CHECK_ARG(desc != nullptr, "hm_encode_bwd_table_tracked: desc is NULL");
+    HM_CHECK_ARG(n >= 0 && cap >= 0, "hm_encode_bwd_table_tracked: negative count");
+    HM_CHECK_ARG(frac_mode == HM_FRAC_REFERENCE || frac_mode == HM_FRAC_TRILINEAR, "hm_encode_bwd_table_tracked: bad frac_mode");
+    HM_CHECK_ARG(d_feat_stride >= desc->lv.L * desc->lv.F, "hm_encode_bwd_table_tracked: d_feat_stride < L*F");
+    HM_CHECK_ARG(desc->total_rows < ((uint64_t)1 << 31), "hm_encode_bwd_table_tracked: table too large for 32-bit row ids");
+    if (n == 0) return HM_OK;
+    HM_CHECK_ARG(x && d_feat && d_table && touched_bits && touched_count && touched_rows,
+                 "hm_encode_bwd_table_tracked: NULL pointer");
+    const int64_t threads = n * desc->lv.L * 8;
+    const int64_t grid = (threads + kThreads - 1) / kThreads;
+    HM_CHECK_ARG(grid <= 0x7fffffffLL, "hm_encode_bwd_table_tracked: n too large for one launch");
+    if (frac_mode == HM_FRAC_REFERENCE)
+        hipLaunchKernelGGL(encode_bwd_table_tracked_kernel<HM_FRAC_REFERENCE>, dim3((unsigned)grid), dim3(kThreads), 0,
+                           as_stream(stream), desc->lv, x, n, d_feat, d_feat_stride, d_table, touched_bits,
+                           touched_count, touched_rows, cap);
+    else
+        hipLaunchKernelGGL(encode_bwd_table_tracked_kernel<HM_FRAC_TRILINEAR>, dim3((unsigned)grid), dim3(kThreads), 0,
+                           as_stream(stream), desc->lv, x, n, d_feat, d_feat_stride, d_table, touched_bits,
+                           touched_count, touched_rows, cap);
+    HM_CHECK_LAUNCH("hm_encode_bwd_table_tracked");
     return HM_OK;
 }
 

@@ -72,7 +72,7 @@ class MultiResHashGridMLP(nn.Module):
         self.table = nn.Parameter(torch.cat(chunks, 0).to(DEVICE))
         self.freq_encoding = self.freq_encoding.to(DEVICE)
         self.embeddings_dim = in_dim + n_levels * max_points_per_level + (self.freq_encoding.embeddings_dim - in_dim)
-        self.grad_collector = None   # parallel.PointGradExchange when the table gradient is exchanged sparsely
+        self.grad_collector = None   # parallel.TouchedRowExchange when the table gradient is exchanged sparsely
         self.fused_input_grad = True  # False: d/dx of the Fourier columns through torch's elementwise autograd
         self._register_state_dict_hook(MultiResHashGridMLP._split_table_hook)
         self._register_load_state_dict_pre_hook(self._fuse_table_hook)

@@ -82,11 +82,31 @@ class FourierFilterBanks(nn.Module):
         d.pop("_nffb_packed", None)
         return d
 
+    def _fused_ok(self):
+        """True when hm_nffb_fwd covers this configuration: its kernel hard-codes the include_input row layout
+        (3 + 8 + 8L columns), L Fourier channels in the grid's B, 2^m positional frequencies, F = 2 and L in {6, 8},
+        and reads contiguous fp32 parameters in place.  Everything else takes the torch expression below."""
+        L = self.n_levels
+        if not (L in (6, 8) and self.max_points_per_level == 2 and self.include_input
+                and self.embeddings_dim == self.num_inputs + 8 + 8 * L):
+            return False
+        B = getattr(getattr(self.grid_enc, "freq_encoding", None), "B", None)
+        if B is None or tuple(B.shape) != (3, L) or not self.grid_enc.table.is_cuda:
+            return False
+        ps = [self.out_layer.weight, self.out_layer.bias]
+        if self.modulationApplied:
+            lt = self.StyleAttentionBlock.linear_transform
+            ps += [lt.weight, lt.bias]
+        for l in range(L - 1):
+            lin = getattr(self, "ff_lin" + str(l))
+            ps += [lin.weight, lin.bias]
+        return all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in ps)
+
     def _needs_graph(self, input):
         return torch.is_grad_enabled() and (input.requires_grad or any(p.requires_grad for p in self.parameters()))
 
     def forward(self, input: torch.Tensor, compute_grad=False) -> torch.Tensor:
-        if input.is_cuda and self.n_levels in (6, 8) and self.max_points_per_level == 2 and not self._needs_graph(input):
+        if input.is_cuda and not self._needs_graph(input) and self._fused_ok():
             return ops.nffb_fwd(self, input.reshape(-1, self.num_inputs))
         x = input / self.bound
         u = (input + self.bound) / (2 * self.bound)

@@ -133,8 +133,7 @@ class ImplicitNetwork(nn.Module):
     def _nffb_embedder(self):
         """the FourierFilterBanks module ('FFB' / 'StyleModNFFB') when its fused kernel covers the configuration"""
         emb = getattr(getattr(self, "embed_model", None), "embedder_obj", None)
-        if emb is not None and type(emb).__name__ == "FourierFilterBanks" and emb.n_levels in (6, 8) \
-                and emb.max_points_per_level == 2:
+        if emb is not None and type(emb).__name__ == "FourierFilterBanks" and emb._fused_ok():
             return emb
         return None
 

@@ -160,8 +160,8 @@ class _HashFeatures(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             d_feat = d_out[:, ctx.hoff:] if ctx.hoff else d_out
             if ctx.collector is not None and ctx.collector.active:
-                # data-parallel run with the sparse exchange (parallel.PointGradExchange): the contribution stays
-                # (points, feature gradients); the dense table gradient is formed once, from ALL ranks' contributions
+                # data-parallel static step (parallel.TouchedRowExchange): the collector scatters into ITS static dense
+                # gradient (bound as table.grad) and lists the touched rows for the exchange; autograd gets nothing
                 ctx.collector.add(x, d_feat)
                 d_table = None
             else:

@@ -51,9 +51,15 @@ def optimizer_state_to_reference(model, sd):
             continue
         state[j] = {name: (v[rows[0]:rows[1]].clone() if (rows is not None and torch.is_tensor(v) and v.dim() > 0) else
                            (v.clone() if torch.is_tensor(v) else v)) for name, v in st.items()}
-    group = dict(sd["param_groups"][0])
+    # every key torch.optim.Adam.step() reads must be in the group, whichever Adam-like optimizer wrote `sd`
+    group = dict(_ADAM_GROUP_DEFAULTS)
+    group.update(sd["param_groups"][0])
     group["params"] = list(range(len(layout)))
     return {"state": state, "param_groups": [group]}
+
+
+_ADAM_GROUP_DEFAULTS = dict(weight_decay=0, amsgrad=False, maximize=False, foreach=None, capturable=False,
+                            differentiable=False, fused=None, decoupled_weight_decay=False)
 
 
 def optimizer_state_from_reference(model, sd):

@@ -8,7 +8,9 @@ depends on a device->host read.  The first calls run eagerly (warm-up on a side 
 kernels of [forward + loss + backward] and of [clip + Adam] are captured once with
 torch.cuda.CUDAGraph (hipGraph underneath) and replayed; only the two CPU-generator draws the reference
 makes per iteration (eikonal samples, closest-approach fractions) are copied in before each replay.
-With more than one rank the RCCL all-reduce runs eagerly between the two graphs.
+With more than one rank the gradient exchange sits between the two graphs: parallel.StaticGradExchange has its device
+work (payload packing, flat bucket, dense-gradient assembly) captured INTO the two graphs, so only its two collectives
+run eagerly; a plain parallel.GradAllReducer (dense all-reduce) runs eagerly as a whole.
 """
 import os
 
@@ -23,12 +25,19 @@ class GraphedTrainStep:
                  sync_each_step=None):
         self.model, self.loss_fn, self.opt, self.reducer = model, loss_fn, optimizer, reducer
         self.max_norm, self.warmup_left, self.use_graph = max_norm, warmup, use_graph
+        self.static_exchange = reducer is not None and hasattr(reducer, "pack")   # parallel.StaticGradExchange
+        if self.static_exchange and reducer.opt is None:
+            reducer.opt = optimizer      # it points the optimizer at the flat, all-reduced gradient bucket
         if sync_each_step is None:
             # default: replays run ahead of the host.  The round-1 replay fault came from MEMSET / MEMCPY graph nodes;
             # the captured iteration now holds kernel nodes only (tests/test_graph_step_gpu.py asserts it), and
-            # 2 x 600 no-sync steps at the bench configuration ran clean.  HM_GRAPH_SYNC=1 restores the
-            # per-step device synchronisation for debugging.
-            sync_each_step = os.environ.get("HM_GRAPH_SYNC", "0") == "1"
+            # 2 x 600 no-sync steps at the bench configuration ran clean.  With a reducer whose device work
+            # is NOT captured (GradAllReducer: copies, memsets and allocator traffic run eagerly between the replays -
+            # the pattern of the round-1 fault) the per-step synchronisation stays on; StaticGradExchange leaves only
+            # its two collectives between the graphs (600-step run-ahead rehearsal: DESIGN.md section 6).
+            # HM_GRAPH_SYNC=1 / 0 overrides either way.
+            env = os.environ.get("HM_GRAPH_SYNC")
+            sync_each_step = (env == "1") if env is not None else (reducer is not None and not self.static_exchange)
         self.sync_each_step = sync_each_step
         self.g_fb = self.g_opt = None
         self.side = None
@@ -66,19 +75,41 @@ class GraphedTrainStep:
     def _fwd_bwd(self):
         for ex in self._sparse():
             ex.begin_step()
+        if self.static_exchange:
+            self.reducer.begin_step()
         s = self.static
         out = self.model.forward_static(s["input"], s["eik"], s["steps"])
         lo = idr_loss_terms(out, s["rgb"], self.loss_fn.eikonal_weight, self.loss_fn.mask_weight, self.loss_fn.alpha)
         lo["loss"].backward()
+        if self.static_exchange:
+            self.reducer.pack()          # payloads + flat bucket: kernels, part of the captured forward/backward graph
         return out, lo
 
+    def _exchange(self):
+        """what runs between the two graphs"""
+        if self.reducer is None:
+            return
+        if self.static_exchange:
+            self.reducer.communicate()   # the two collectives, nothing else
+        else:
+            self.reducer()
+
     def _update(self):
+        if self.static_exchange:
+            self.reducer.apply()         # dense table gradients from all ranks' lists (captured)
         if not getattr(self.opt, "fused_clip", False):   # training.optim.ClipAdam clips inside its own pass
+            if self.static_exchange:
+                raise ValueError("GraphedTrainStep: StaticGradExchange needs training.optim.ClipAdam (it reads the "
+                                 "averaged gradients from the flat bucket)")
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=self.max_norm)
         self.opt.step()
+        if self.static_exchange:
+            self.reducer.finish()
 
     def _eager_iteration(self):
         self.opt.zero_grad(set_to_none=True)
+        if self.static_exchange:
+            self.reducer.attach()
         out, lo = self._fwd_bwd()
         # keep VALUES only: a live autograd graph would keep this iteration's AccumulateGrad nodes (bound to
         # this stream) alive, and a later capture on another stream would then leave the gradient
@@ -86,8 +117,7 @@ class GraphedTrainStep:
         self.out = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}
         self.loss_out = {k: v.detach() for k, v in lo.items()}
         del out, lo
-        if self.reducer is not None:
-            self.reducer()
+        self._exchange()
         self._update()
 
     # -- driver -------------------------------------------------------------------------------
@@ -130,6 +160,8 @@ class GraphedTrainStep:
             self.opt.zero_grad(set_to_none=True)
             for ex in self._sparse():      # their dense gradients are static tensors the optimizer graph reads
                 ex.attach()
+            if self.static_exchange:
+                self.reducer.attach()
             torch.cuda.synchronize()
             # with RCCL alive its watchdog thread polls events; only this thread's calls must obey capture rules
             mode = "thread_local" if (torch.distributed.is_available() and torch.distributed.is_initialized()) else "global"
@@ -155,12 +187,18 @@ class GraphedTrainStep:
                 if self.reducer is not None and hasattr(self.reducer, "assume_dense"):
                     self.reducer.assume_dense = True     # every replay produces every gradient on every rank
                     self.reducer.frozen_grads = True     # ... into the tensors g_opt was captured on
+                if self.static_exchange:
+                    self.reducer.freeze()                # bucket / payload layout is what the graphs were captured on
                 if hasattr(self.opt, "frozen_grads"):
                     self.opt.frozen_grads = True
                 if dump:
                     g_fb.debug_dump(os.path.join(dump, "g_fb.dot"))
                     g_opt.debug_dump(os.path.join(dump, "g_opt.dot"))
             except RuntimeError as err:  # keep training eagerly rather than die on a capture restriction
+                if self.reducer is not None:
+                    # a multi-rank run where ONE rank falls back to eager steps would leave the ranks with different
+                    # exchange layouts (and different collectives per step): fatal, not a warning
+                    raise RuntimeError(f"HIP-graph capture failed on a data-parallel rank: {err}") from err
                 import warnings
                 warnings.warn(f"HIP-graph capture failed ({err}); continuing with the eager static step")
                 self.use_graph = False
@@ -170,8 +208,7 @@ class GraphedTrainStep:
                 return self.out, self.loss_out
 
         self.g_fb.replay()
-        if self.reducer is not None:
-            self.reducer()
+        self._exchange()
         self.g_opt.replay()
         # the replayed optimizer wrote the parameters behind torch's back: the packed SDF images now in memory were
         # built (inside g_fb) from the PREVIOUS values - any eager user (net.sdf, eval, plots) must re-pack

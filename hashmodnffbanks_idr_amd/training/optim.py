@@ -22,9 +22,17 @@ class ClipAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
             raise ValueError("ClipAdam: invalid hyper-parameter")
-        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps))
+        # the group carries every key torch.optim.Adam's own group has (at their Adam defaults), so an
+        # OptimizerParameters/*.pth written from here is continued by the reference's torch.optim.Adam
+        # (idr_train.py:128,151-156: load_state_dict, then step() reads group['weight_decay'] etc.)
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0, amsgrad=False,
+                                      maximize=False, foreach=None, capturable=False, differentiable=False,
+                                      fused=None, decoupled_weight_decay=False))
         self.max_norm = max_norm
         self.frozen_grads = False  # GraphedTrainStep sets it after capture: .grad tensors must keep their addresses
+        # parameter -> tensor holding its gradient instead of .grad (parallel.StaticGradExchange: views of the flat,
+        # all-reduced bucket - the averaged gradients are read where the collective left them, nothing is copied back)
+        self.grad_override = {}
         self._dev_state = {}     # device -> (per-parameter step counters int64[n_params], scratch float[2])
         self.last_grad_norm = None   # device scalar: total gradient norm before clipping (of the last step)
 
@@ -49,28 +57,38 @@ class ClipAdam(torch.optim.Optimizer):
             # the global gradient norm spans all groups; one hyper-parameter set keeps it a single pass
             raise NotImplementedError("ClipAdam supports one parameter group (as the reference runner uses)")
         grp = self.param_groups[0]
-        plist = [(k, p) for k, p in enumerate(grp["params"]) if p.grad is not None]
+        if grp.get("weight_decay", 0) or grp.get("amsgrad", False) or grp.get("maximize", False):
+            raise NotImplementedError("ClipAdam implements plain Adam (weight_decay = 0, no amsgrad / maximize), the "
+                                      "reference runner's optimizer")
+        ovr = self.grad_override
+        plist = [(k, p) for k, p in enumerate(grp["params"]) if (p.grad is not None or p in ovr)]
         if not plist:
             return loss
         dev = plist[0][1].device
         steps, scratch = self._device_state(dev)
         table = (_lib.AdamTensor * len(plist))()
         for i, (k, p) in enumerate(plist):
-            require_gpu(p, p.grad)
-            if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or p.device != dev:
+            grad = ovr.get(p)
+            if grad is not None:
+                if grad.shape != p.shape or not grad.is_contiguous():
+                    raise ValueError("ClipAdam: grad_override tensors must be contiguous and shaped like their parameter")
+            else:
+                grad = p.grad
+            require_gpu(p, grad)
+            if p.dtype != torch.float32 or grad.dtype != torch.float32 or p.device != dev:
                 raise TypeError("ClipAdam: fp32 parameters on one device only")
             if not p.is_contiguous():
                 raise ValueError("ClipAdam: parameters must be contiguous")
-            if not p.grad.is_contiguous():
+            if not grad.is_contiguous():
                 if self.frozen_grads:
                     raise RuntimeError("ClipAdam: a gradient became non-contiguous after the step was captured")
-                p.grad = p.grad.contiguous()
+                grad = p.grad = p.grad.contiguous()
             st = self.state[p]
             if not st:
                 st["step"] = None    # materialised by state_dict(); the live counters sit in one device array
                 st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-            table[i] = _lib.AdamTensor(p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(),
+            table[i] = _lib.AdamTensor(p.data_ptr(), grad.data_ptr(), st["exp_avg"].data_ptr(),
                                        st["exp_avg_sq"].data_ptr(), steps.data_ptr() + 8 * k, p.numel())
         b1, b2 = grp["betas"]
         need = check(lib().hm_adam_scratch_floats(C.cast(table, C.c_void_p), len(plist)))

@@ -458,6 +458,42 @@ HM_API int64_t hm_adam_scratch_floats(const hm_adam_tensor *tensors, int n_tenso
 HM_API int hm_adam_step(const hm_adam_tensor *tensors, int n_tensors, float lr, float beta1, float beta2, float eps,
                         float max_norm, float *scratch_dev, void *stream);
 
+/* ---- data-parallel gradient exchange (device side) ---------------------------------------------------
+ * The reference runner is single-GPU (training/idr_train.py:92-93,278-321): there is no interface to
+ * replace, the exchange is the build's own addition in the place the north star names - between loss.backward()
+ * (idr_train.py:302) and clip_grad_norm_ / optimizer.step() (:306-308).  Everything except the collectives themselves
+ * (RCCL, issued by the host side) is a kernel below, so that it can be captured into the training step's graphs.
+ *
+ * Hash-table gradient.  hm_encode_bwd_table_tracked is hm_encode_bwd_table (same atomics into d_table) that also lists
+ * each row it touches ONCE: touched_bits [ceil(total_rows/32)] one claim bit per row (all zero between steps),
+ * touched_count [1] the number of listed rows, touched_rows [cap] their ids in the fused table.  Several calls of one
+ * step share the three buffers.  hm_rows_pack turns the list into this rank's payload [cap, 1+F] int32 (row id, then
+ * the F gradient values as fp32 bits; entries beyond the count carry row -1), zeroing the listed rows of d_table and
+ * their claim bits; status[0] (optional) receives the overflow if more than `cap` rows were claimed.  After ONE
+ * all-gather of the payloads hm_rows_apply adds list r = lists + r*list_stride (r = 0..n_lists-1, one launch each, in
+ * that order) into d_table scaled by `scale` (1/world): rows are unique inside a list, so plain read-modify-writes
+ * suffice and every replica sums every row in the same (rank) order - bitwise identical replicas, no sort.
+ * hm_rows_clear (after the optimizer step) zeroes the rows named by all lists again and resets *touched_count.      */
+HM_API int hm_encode_bwd_table_tracked(const hm_grid_desc *desc, const float *x, int64_t n, const float *d_feat,
+                                       int64_t d_feat_stride, float *d_table, int frac_mode, uint32_t *touched_bits,
+                                       int32_t *touched_count, int32_t *touched_rows, int64_t cap, void *stream);
+HM_API int hm_rows_pack(float *d_table, int n_features, const int32_t *touched_rows, const int32_t *touched_count,
+                        int64_t cap, uint32_t *touched_bits, int32_t *payload, int32_t *status, void *stream);
+HM_API int hm_rows_apply(float *d_table, int64_t total_rows, int n_features, const int32_t *lists, int64_t cap,
+                         int64_t list_stride, int n_lists, float scale, void *stream);
+HM_API int hm_rows_clear(float *d_table, int64_t total_rows, int n_features, const int32_t *lists, int64_t cap,
+                         int64_t list_stride, int n_lists, int32_t *touched_count, void *stream);
+
+/* MLP gradients -> one flat bucket in ONE launch (the bucket is all-reduced in place; hm_adam_step then reads the
+ * averaged gradients from it).  items is a [host] array, copied by value into the kernel arguments.              */
+#define HM_COPY_MAX_ITEMS 96
+typedef struct hm_copy_item {
+    const float *src;
+    float *dst;
+    int64_t numel;
+} hm_copy_item;
+HM_API int hm_multi_copy_f32(const hm_copy_item *items, int n_items, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

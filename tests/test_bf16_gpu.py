@@ -139,3 +139,128 @@ def test_loss_curve_50_steps_bf16_vs_fp32():
     # last-bit noise of the atomics), so the per-step bound is that spread plus 2 %
     assert rel_w.max() <= 0.02 + spread_w.max()
     assert rel.max() <= 0.02 + 2 * spread.max()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE configs[4] as bench.py's config5_leg runs it: StyleModNFFB embedder + bf16 coarse scans, i.e.
+# hm_nffb_fwd -> hm_sdf_fwd_emb_bf16 and hm_trace_forward_nffb with coarse_bf16 = 1 (reference embedder:
+# model/embeddings/nffb3d.py:122-194, style_Attention/styleMod.py:16-43; no reduced-precision reference exists)
+# ---------------------------------------------------------------------------------------------------------------
+def _c5_model(golden):
+    from helpers import make_idr_nffb
+    g = golden("idr_step_C5")
+    return g, make_idr_nffb(str(g["embed_type"]), int(g["seed"]))
+
+
+def test_bf16_emb_kernel_against_fp32_kernel_on_stylemod(golden):
+    """hm_sdf_fwd_emb_bf16 vs hm_sdf_fwd_emb on the embedding rows of the StyleModNFFB network of idr_step_C5.npz:
+    28 841 + ragged points, device-side count, run_min gate"""
+    from hashmodnffbanks_idr_amd import ops
+    g, model = _c5_model(golden)
+    net = model.implicit_network
+    assert net._hash_embedder() is None and net._nffb_embedder() is not None
+    net.bf16_coarse_search = True
+    n = 96 * 300 + 41
+    x = (torch.rand(n, 3, device="cuda", generator=torch.Generator(device="cuda").manual_seed(12)) * 2 - 1)
+    with torch.no_grad():
+        e = ops.nffb_fwd(net._nffb_embedder(), x)
+        pk = net.packed_weights()
+        assert pk.has_bf16
+        ref = ops.sdf_fwd_emb(pk, e, sdf_only=True)
+        assert torch.equal(ref, net.sdf(x))                       # the product's fp32 route is exactly this pair of calls
+        got = ops.sdf_fwd_emb_bf16(pk, e)
+    err = (got - ref).abs()
+    rel = err / (ref.abs() + 1e-2)
+    flips = int(((got < 0) != (ref < 0)).sum())
+    print(f"StyleModNFFB bf16 vs fp32 SDF on {n} embedding rows: max |d| {err.max().item():.3e}, mean |d| "
+          f"{err.mean().item():.3e}, max |d|/(|sdf| + 0.01) {rel.max().item():.3e}; sign flips {flips}")
+    assert torch.isfinite(got).all()
+    assert err.max().item() <= 5e-3 and err.mean().item() <= 5e-4
+    assert flips <= 0.002 * n
+    n_dev = torch.tensor([5000], dtype=torch.int32, device="cuda")
+    with torch.no_grad():
+        part = ops.sdf_fwd_emb_bf16(pk, e, n_dev=n_dev)
+        assert torch.equal(part[:5000], got[:5000])
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_tracer_with_bf16_coarse_scans_on_stylemod(golden, mode):
+    """hm_trace_forward_nffb with coarse_bf16 = 1 vs 0 at the C5 shape (2048 rays of idr_step_C5.npz)"""
+    from hashmodnffbanks_idr_amd.model.ray_tracing import RayTracing
+    from hashmodnffbanks_idr_amd.utils import rend_util
+    g, model = _c5_model(golden)
+    net = model.implicit_network
+    net.eval()
+    inp = {k: torch.from_numpy(g[k]).cuda() for k in ("intrinsics", "uv", "pose", "object_mask")}
+    dirs, cam = rend_util.get_camera_params(inp["uv"], inp["pose"], inp["intrinsics"])
+    om = inp["object_mask"].reshape(-1)
+    outs = []
+    for coarse in (False, True):
+        net.bf16_coarse_search = coarse
+        rt = RayTracing(1.0, 5.0e-5, 0.5, 3, 10, 100, 8).cuda()
+        rt.train(mode == "train")
+        rt.steps_override = torch.from_numpy(g["s0:draw0"])
+        with torch.no_grad():
+            outs.append(rt(sdf=net.sdf, cam_loc=cam, object_mask=om, ray_directions=dirs))
+        st = rt.last_stats
+        assert st["unfinished"] == 0 and st["nonfinite"] == 0 and st["sdf_evals"] > 2048
+    (p1, m1, d1), (p2, m2, d2) = outs
+    flips = int((m1 != m2).sum())
+    hit = (m1 & m2 & om) if mode == "train" else (m1 & m2)
+    dd = (d1 - d2).abs()
+    print(f"StyleModNFFB bf16 coarse tracer [{mode}]: {flips} / {m1.numel()} mask flips; {int(hit.sum())} common hits, "
+          f"|dist| diff median {dd[hit].median().item():.2e}, 99 % {dd[hit].quantile(0.99).item():.2e}")
+    assert flips <= 0.01 * m1.numel()
+    assert int(hit.sum()) > 100
+    assert dd[hit].median().item() <= 1e-4 and dd[hit].quantile(0.9).item() <= 1e-2
+    net.bf16_coarse_search = False
+    with torch.no_grad():
+        res_bf16, res_fp32 = net.sdf(p2[hit]).abs(), net.sdf(p1[hit]).abs()
+    print(f"    surface residual |sdf| at the hits: bf16-coarse run median {res_bf16.median().item():.2e} / 99 % "
+          f"{res_bf16.quantile(0.99).item():.2e};  fp32 run median {res_fp32.median().item():.2e} / 99 % "
+          f"{res_fp32.quantile(0.99).item():.2e}")
+    assert res_bf16.quantile(0.99).item() <= max(3e-3, 3 * res_fp32.quantile(0.99).item())
+    other = ~hit & (m1 == m2)
+    if bool(other.any()):
+        with torch.no_grad():
+            s1, s2 = net.sdf(p1[other]), net.sdf(p2[other])
+        ds = (s1 - s2).abs()
+        print(f"    {int(other.sum())} rays that end on an argmin sample: |sdf(p_bf16) - sdf(p_fp32)| median "
+              f"{ds.median().item():.2e}, max {ds.max().item():.2e}")
+        assert ds.quantile(0.99).item() <= 5e-3
+
+
+def test_loss_curve_50_steps_bf16_vs_fp32_on_stylemod(golden):
+    """SURVEY.md 8(d) on the configuration bench.py's config5_leg times: StyleModNFFB, 2048 rays, captured step,
+    50 steps with lr 1e-4 - 10-step window means of the bf16-coarse run within 2 % of the fp32 run"""
+    from hashmodnffbanks_idr_amd.model.loss import IDRLoss
+    from hashmodnffbanks_idr_amd.training.graph_step import GraphedTrainStep
+    from hashmodnffbanks_idr_amd.training.optim import ClipAdam
+    curves = []
+    for coarse in (False, True, False):
+        g, model = _c5_model(golden)
+        model.train()
+        model.implicit_network.bf16_coarse_search = coarse
+        inp = {k: torch.from_numpy(g[k]).cuda() for k in ("intrinsics", "uv", "pose", "object_mask")}
+        gt = {"rgb": torch.from_numpy(g["rgb_gt"]).cuda()}
+        loss_fn = IDRLoss(eikonal_weight=0.1, mask_weight=100.0, alpha=50.0)
+        stepper = GraphedTrainStep(model, loss_fn, ClipAdam(model.parameters(), lr=1e-4), warmup=2)
+        torch.manual_seed(9)
+        losses = []
+        for _ in range(50):
+            _, lo = stepper.step(inp, gt)
+            losses.append(lo["loss"].clone())
+        curves.append(torch.stack(losses).cpu().numpy())
+        assert stepper.g_fb is not None
+        st = model.ray_tracer.last_stats
+        assert st["nonfinite"] == 0 and st["unfinished"] == 0
+    a, b, a2 = curves
+    win = lambda c: c.reshape(5, 10).mean(1)          # noqa: E731
+    rel, spread = np.abs(a - b) / np.abs(a), np.abs(a - a2) / np.abs(a)
+    rel_w, spread_w = np.abs(win(a) - win(b)) / win(a), np.abs(win(a) - win(a2)) / win(a)
+    print("fp32 :", [f"{v:.5f}" for v in a[[0, 1, 2, 5, 10, 25, 49]]])
+    print("bf16 :", [f"{v:.5f}" for v in b[[0, 1, 2, 5, 10, 25, 49]]])
+    print(f"StyleModNFFB 50-step loss curves fp32 vs bf16-coarse: per-step max rel diff {rel.max():.3e} (fp32 vs fp32: "
+          f"{spread.max():.3e}); 10-step windows max rel diff {rel_w.max():.3e} (fp32 vs fp32: {spread_w.max():.3e})")
+    assert rel_w.max() <= 0.02 + spread_w.max()
+    assert rel.max() <= 0.02 + 2 * spread.max()

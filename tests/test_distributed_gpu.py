@@ -56,12 +56,13 @@ def _worker(rank, world, port, out_dir, sparse=False):
     model, loss_fn, bench = _build()
     inp, gt = _shard_inputs(bench, rank)
     opt = ClipAdam(model.parameters(), lr=LR, max_norm=1.0)
-    exchanges = []
-    if sparse:   # table gradients as (point, feature-gradient) pairs instead of the dense all-reduce
-        exchanges = [parallel.PointGradExchange(model.implicit_network.embed_model.embedder_obj),
-                     parallel.PointGradExchange(model.rendering_network.embed_model.embedder_obj)]
-    stepper = GraphedTrainStep(model, loss_fn, opt, parallel.GradAllReducer(model.parameters(), sparse=exchanges),
-                               warmup=2)
+    if sparse:   # the product's exchange: table gradients as (row, value) lists, device work inside the two graphs
+        reducer = parallel.StaticGradExchange(model.parameters(),
+                                              tables=[model.implicit_network.embed_model.embedder_obj,
+                                                      model.rendering_network.embed_model.embedder_obj])
+    else:        # dense all-reduce of every gradient
+        reducer = parallel.GradAllReducer(model.parameters())
+    stepper = GraphedTrainStep(model, loss_fn, opt, reducer, warmup=2)
     torch.manual_seed(100 + rank)
     rec = {"loss": [], "evals": [], "nonfinite": [], "unfinished": []}
     for _ in range(STEPS):
@@ -72,6 +73,12 @@ def _worker(rank, world, port, out_dir, sparse=False):
         rec["nonfinite"].append(int(st["nonfinite"]))
         rec["unfinished"].append(int(st["unfinished"]))
     rec["graph"] = stepper.g_fb is not None
+    if sparse:
+        reducer.check()                                   # no touched row missed its payload
+        torch.cuda.synchronize()
+        for t in reducer.tables:                          # between steps the static dense gradients are all zero again
+            assert int(torch.count_nonzero(t.dense)) == 0 and int(torch.count_nonzero(t.bits)) == 0
+            assert int(t.count.item()) == 0
     rec["params"] = {n: p.detach().cpu() for n, p in model.named_parameters()}
     torch.save(rec, os.path.join(out_dir, f"rank{rank}.pt"))
     torch.distributed.barrier()
@@ -141,3 +148,50 @@ def test_two_gloo_ranks_follow_the_averaged_gradient_trajectory(sparse):
         assert diff.max().item() <= 2.5 * STEPS * LR, n
         assert diff.mean().item() <= 0.05 * LR, (n, diff.mean().item())
     print(f"max parameter difference after {STEPS} steps: {worst:.2e}")
+
+
+def test_static_exchange_single_process_equals_plain_step():
+    """with the table-gradient collector attached and NO process group the gradient must not be dropped -
+    StaticGradExchange then applies the rank's own payload as the only list.  The captured step with the exchange must
+    follow the captured step without it (same seeds; the two differ only in the order of fp32 atomic additions)."""
+    from hashmodnffbanks_idr_amd import parallel
+    from hashmodnffbanks_idr_amd.training.graph_step import GraphedTrainStep
+    from hashmodnffbanks_idr_amd.training.optim import ClipAdam
+    assert not torch.distributed.is_initialized()
+    runs = []
+    for with_exchange in (False, True):
+        model, loss_fn, bench = _build()
+        inp, gt = _shard_inputs(bench, 0)
+        opt = ClipAdam(model.parameters(), lr=LR, max_norm=1.0)
+        reducer = None
+        if with_exchange:
+            reducer = parallel.StaticGradExchange(model.parameters(),
+                                                  tables=[model.implicit_network.embed_model.embedder_obj,
+                                                          model.rendering_network.embed_model.embedder_obj])
+        stepper = GraphedTrainStep(model, loss_fn, opt, reducer, warmup=2)
+        t_init = model.implicit_network.embed_model.embedder_obj.table.detach().clone()
+        torch.manual_seed(100)
+        losses, norms = [], []
+        for _ in range(STEPS):
+            _, lo = stepper.step(inp, gt)
+            losses.append(float(lo["loss"].item()))
+            norms.append(float(opt.last_grad_norm.item()))
+        assert stepper.g_fb is not None
+        if with_exchange:
+            reducer.check()
+            emb = model.implicit_network.embed_model.embedder_obj
+            assert emb.table.grad.data_ptr() == reducer.tables[0].dense.data_ptr()
+            assert int(torch.count_nonzero(reducer.tables[0].dense)) == 0
+        # the table was trained: Adam moves a row by ~lr per step once it has seen a gradient
+        assert int(((model.implicit_network.embed_model.embedder_obj.table.detach() - t_init).abs() > 0.5 * LR).sum()) > 1000
+        runs.append((losses, norms, {n: p.detach().clone() for n, p in model.named_parameters()}))
+    (l0, n0, p0), (l1, n1, p1) = runs
+    print("loss without / with exchange:", [f"{v:.6f}" for v in l0], [f"{v:.6f}" for v in l1])
+    print("grad norm without / with exchange:", [f"{v:.6f}" for v in n0], [f"{v:.6f}" for v in n1])
+    for a, b in zip(l0, l1):
+        assert abs(a - b) <= 1e-4 * abs(a) + 1e-7
+    for a, b in zip(n0, n1):
+        assert abs(a - b) <= 1e-4 * abs(a) + 1e-7          # the table gradient is in the norm: a dropped one would show
+    tab = "implicit_network.embed_model.embedder_obj.table"
+    assert float((p1[tab] - p0[tab]).abs().max()) <= 2.5 * STEPS * LR
+    assert float((p1[tab] - p0[tab]).abs().mean()) <= 0.05 * LR

@@ -200,6 +200,71 @@ def test_zordered_table_backward(cfg, mode):
     assert abs(got.double().sum().item() - ref.double().sum().item()) <= 1e-5 * ref.double().abs().sum().item()
 
 
+@pytest.mark.parametrize("frac", ["reference", "trilinear"])
+@pytest.mark.parametrize("cfg,n", [("C2", 131072 + 37), ("C2", 200037), ("C4", 131072 + 37), ("C4", 200037)])
+def test_zordered_forward_vs_oracle(cfg, n, frac):
+    """launches >= 131 072 points over tables > 8 MiB take the z-ordered gather (hm_encode_fwd_ws: the kernel the bench's
+    `roofline` object times): ragged last tile, points outside [-1, 1]^3 (the z-slab clamp, hm_encode.hip z_slab) and
+    duplicated points, both weight modes, every row against the C oracle - hash columns bit for bit in reference mode
+    (hashGridEmbedding.py:81-102)"""
+    from hashmodnffbanks_idr_amd import _lib, ops
+    emb, table, B = _embedder(cfg, 78, 0.5, frac)
+    L, T, b, d = P.CONFIGS[cfg]
+    x = P.make_points(6, n, -1.3, 1.3)
+    x[3000:5000] = x[:2000]
+    x[7] = (1.0, -1.0, 1.0)
+    x[8] = (-1.0, 1.0, -1.0)
+    fm = ops.FRAC_MODES[frac]
+    xt = torch.from_numpy(x).cuda()
+    need = _lib.check(_lib.lib().hm_encode_workspace_bytes(emb.desc.handle, n))
+    assert need > 0
+    out = ops.encode_fwd(emb.desc, xt, emb.table.detach(), emb.freq_encoding.B, fm)
+    # the same launch through the tile kernel (no workspace): a second implementation of the same rows
+    tile = torch.empty_like(out)
+    _lib.check(_lib.lib().hm_encode_fwd(emb.desc.handle, _lib.dptr(xt), n, _lib.dptr(emb.table.detach()),
+                                        _lib.dptr(emb.freq_encoding.B), _lib.dptr(tile), emb.desc.E, fm,
+                                        _lib.stream_ptr(xt)))
+    out, tile = out.cpu().numpy(), tile.cpu().numpy()
+    ref = O.encode_fwd(O.Grid(L, T, b, d), x, table, B, fm)
+    nf = 3 + 2 * L
+    if frac == "reference":
+        assert np.array_equal(out[:, nf:], ref[:, nf:]), "z-ordered gather: hash columns differ from the oracle"
+        assert np.array_equal(tile[:, nf:], ref[:, nf:])
+    else:
+        err = np.abs(out[:, nf:] - ref[:, nf:]).max()
+        print(f"z-ordered gather {cfg}/trilinear n={n}: max |d| vs the oracle {err:.3e}")
+        np.testing.assert_allclose(out[:, nf:], ref[:, nf:], rtol=1e-5, atol=1e-6)
+    assert np.array_equal(out[:, :3], x)
+    np.testing.assert_allclose(out[:, :nf], ref[:, :nf], atol=1e-5, rtol=0)
+    assert np.array_equal(out, tile), "z-ordered and tile kernels must produce identical rows"
+
+
+@pytest.mark.parametrize("mode", ["reference", "trilinear"])
+@pytest.mark.parametrize("cfg", ["C2", "C4"])
+def test_zordered_table_backward_vs_oracle(cfg, mode):
+    """the z-ordered scatter against the C oracle's table backward (not only against the repo's own atomic kernel):
+    ragged size, points outside the cube, duplicates"""
+    from hashmodnffbanks_idr_amd import ops
+    L, T, b, d = P.CONFIGS[cfg]
+    res, rows = P.level_table(L, T, b, d)
+    desc = ops.GridDesc(res, rows, 2)
+    n = 200000 + 37
+    x = P.make_points(9, n, -1.3, 1.3)
+    x[2000:4000] = x[:2000]
+    rs = np.random.RandomState(10)
+    gf = rs.standard_normal((n, L * 2)).astype(np.float32)
+    fm = ops.FRAC_MODES[mode]
+    got = ops.encode_bwd_table(desc, torch.from_numpy(x).cuda(), torch.from_numpy(gf).cuda(), fm).cpu().numpy()
+    d_out = np.zeros((n, 3 + 2 * L + 2 * L), np.float32)
+    d_out[:, 3 + 2 * L:] = gf
+    ref = O.encode_bwd_table(O.Grid(L, T, b, d), x, d_out, fm)
+    scale = np.abs(ref).max()
+    err = np.abs(got - ref).max()
+    print(f"z-ordered table backward vs the C oracle {cfg}/{mode}: max |d| {err:.3e} (scale {scale:.3e})")
+    assert err <= 3e-5 * scale
+    assert abs(got.astype(np.float64).sum() - ref.astype(np.float64).sum()) <= 1e-5 * np.abs(ref).astype(np.float64).sum()
+
+
 def _trilinear_torch(x, table, desc):
     """differentiable torch restatement of the trilinear encoder (fp64): floor voxel, 8 hashed corners, product
     weights - the opt-in mode has no counterpart in the reference, so autograd on this expression is the checker"""

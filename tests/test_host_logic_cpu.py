@@ -176,6 +176,46 @@ def test_optimizer_state_from_a_reference_shaped_checkpoint(golden):
         ck.optimizer_state_from_reference(model, bad)
 
 
+def test_saved_optimizer_file_is_continued_by_torch_adam(tmp_path):
+    """the OptimizerParameters file written from a ClipAdam run must be usable by the REFERENCE's
+    torch.optim.Adam (idr_train.py:128,151-156): load_state_dict() into an Adam built over a reference-shaped
+    parameter list (one parameter per hash-grid level), then step() - which reads group['weight_decay'],
+    ['amsgrad'], ['maximize'] ... and raised KeyError before ClipAdam's group carried them."""
+    from hashmodnffbanks_idr_amd.model.implicit_differentiable_renderer import IDRNetwork
+    from hashmodnffbanks_idr_amd.training import checkpoints as ck
+    from hashmodnffbanks_idr_amd.training.optim import ClipAdam
+    torch.manual_seed(6)
+    model = IDRNetwork(idr_conf("tiny"))
+    opt = ClipAdam(model.parameters(), lr=1e-4, max_norm=1.0)
+    for p in model.parameters():                      # Adam state as ClipAdam.step() lays it out (the step itself needs a GPU)
+        if p.requires_grad and p.numel() > 1:
+            opt.state[p] = {"step": None, "exp_avg": torch.full_like(p, 1e-3), "exp_avg_sq": torch.full_like(p, 1e-6)}
+    ck.save_checkpoints(str(tmp_path), 3, model, opt)
+    osd = torch.load(tmp_path / "OptimizerParameters" / "latest.pth", weights_only=True)["optimizer_state_dict"]
+    grp = osd["param_groups"][0]
+    ref_grp = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=1e-4).state_dict()["param_groups"][0]
+    assert set(ref_grp) <= set(grp), sorted(set(ref_grp) - set(grp))
+    # the reference's parameter list: the model's own, with every fused table replaced by its per-level tensors
+    layout = ck._reference_layout(model)
+    own = list(model.parameters())
+    ref_params = []
+    for k, rows in layout:
+        if rows is None:
+            ref_params.append(torch.nn.Parameter(own[k].detach().clone()))
+        else:
+            ref_params.append(torch.nn.Parameter(own[k].detach()[rows[0]:rows[1]].clone()))
+    ref_opt = torch.optim.Adam(ref_params, lr=1e-4)
+    ref_opt.load_state_dict(osd)
+    before = [p.detach().clone() for p in ref_params]
+    for p in ref_params:
+        p.grad = torch.full_like(p, 2e-3)
+    ref_opt.step()                                    # KeyError('weight_decay') before the fix
+    moved = [not torch.equal(a, b.detach()) for a, b in zip(before, ref_params)]
+    assert all(moved)
+    k_tab = [j for j, (k, rows) in enumerate(layout) if rows is not None][0]
+    assert ref_opt.state[ref_params[k_tab]]["exp_avg"].shape == ref_params[k_tab].shape
+
+
 def _rand_rotation(rng):
     q, r = np.linalg.qr(rng.standard_normal((3, 3)))
     q = q @ np.diag(np.sign(np.diag(r)))

@@ -86,7 +86,7 @@ def _sdf_oracle(g, cfg, hidden, fvs):
     return O.SdfOracle(grid, np.concatenate(levels, 0), B, prm)
 
 
-@pytest.mark.parametrize("tag,cfg", [("full", "C1"), ("init", "C1"), ("narrow", "tiny")])
+@pytest.mark.parametrize("tag,cfg", [("full", "C1"), ("init", "C1"), ("narrow", "tiny"), ("C2", "C2")])
 def test_sdf_forward(golden, tag, cfg):
     g = golden(f"sdf_{tag}")
     net = _sdf_oracle(g, cfg, tuple(g["hidden"].tolist()), int(g["fvs"]))
