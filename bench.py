@@ -317,6 +317,41 @@ def mlp_bf16_roofline(net, log2_n=18, iters=5, warmup=2):
             "note": "bound by the per-CU weight stream (1 KB of bf16 weights per 6 MFMAs), not by the matrix pipe"}
 
 
+def mlp_split_roofline(net, kind, log2_n=18, iters=5, warmup=2):
+    """split-operand variant of the fused SDF kernel (csrc/hm_sdf_split.hip): same flop count as the fp32 kernel; the
+    matrix work is 3 MFMAs of the 16-bit pipe per product, priced against the dense 16-bit MFMA peak (2.5 PFLOP/s)"""
+    from hashmodnffbanks_idr_amd import ops
+    dev = next(net.parameters()).device
+    n = 1 << log2_n
+    g = torch.Generator(device="cpu").manual_seed(99)
+    x = (torch.rand((n, 3), generator=g) * 2 - 1).to(dev)
+    net.coarse_split = kind
+    emb = net._hash_embedder()
+    pk = net.packed_weights()
+    run = lambda: ops.sdf_fwd_split(emb.desc, pk, x, emb.table.detach(), emb.freq_encoding.B)   # noqa: E731
+    for _ in range(warmup):
+        run()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for s, e in evs:
+        s.record()
+        run()
+        e.record()
+    torch.cuda.synchronize()
+    ms = np.asarray([s.elapsed_time(e) for s, e in evs])
+    avg_ms = float(ms.mean())
+    flops = 2.0 * (SDF_MAC_PER_POINT - 512 * 256)
+    tf = n * flops / (avg_ms * 1e-3) / 1e12
+    net.coarse_split = None
+    return {"bound": "mfma", "achieved": round(3 * tf, 2), "peak": 2500.0, "unit": "TFLOP/s",
+            "frac": round(3 * tf / 2500.0, 4), "traffic": None, "kernel": f"sdf_fwd_split_kernel<{kind}>",
+            "units_per_launch": n, "flop_per_unit": flops, "executed_flop_per_unit": 3 * flops,
+            "fp32_equivalent_TFLOP/s": round(tf, 2), "avg_launch_ms": round(avg_ms, 4),
+            "points_per_s": round(n / (avg_ms * 1e-3), 1),
+            "note": "achieved = EXECUTED 16-bit MFMA flops (three products per fp32-equivalent product); "
+                    "fp32_equivalent_TFLOP/s = the network's flops / time, comparable with roofline_mlp"}
+
+
 def cpu_baseline(model, n_rays=256, reps=2):
     """oracle/torch_ref.py (port of the reference's PyTorch path) on the host cores: the SAME
     parameters the GPU run ended with (so both see the same surface / amount of ray-marching work),
@@ -434,7 +469,7 @@ def _spawn_ranks(args):
     return subprocess.run(cmd, env=env).returncode
 
 
-def _side_leg(cfg, device, bf16, steps=6, warmup=3, sampler_head=0):
+def _side_leg(cfg, device, bf16, steps=6, warmup=3, sampler_head=0, split=None):
     """short fixed-weights leg of another BASELINE configuration on rank 0 (reported beside the headline)"""
     import types
     from hashmodnffbanks_idr_amd.model.loss import IDRLoss
@@ -443,6 +478,7 @@ def _side_leg(cfg, device, bf16, steps=6, warmup=3, sampler_head=0):
     a = types.SimpleNamespace(no_graph=False, warmup=warmup, steps=steps, rays=rays)
     model = _build(cfg, device, 0.0)
     model.implicit_network.bf16_coarse_search = bool(bf16)
+    model.implicit_network.coarse_split = split
     model.ray_tracer.sampler_head = sampler_head      # 0, like the headline: the reference's evaluation count
     inp, gt = synthetic_batch(1234, rays, device)
     torch.manual_seed(100)
@@ -455,7 +491,9 @@ def _side_leg(cfg, device, bf16, steps=6, warmup=3, sampler_head=0):
                 "sampler_head": sampler_head, "sdf_evals_per_step": stats}
     return {"value": round(rays * steps / dt, 1), "unit": "rays/s", "ms_per_step": round(dt / steps * 1e3, 3),
             "steps": steps, "rays": rays, "workload": f"{et} embedder L={L} T=2^{T} F=2, {rays} rays, weights at init (lr = 0)",
-            "dtype": "bf16 coarse ray-search scans, f32 elsewhere" if bf16 else "f32",
+            "dtype": (f"{split} split operands (hi + lo 16-bit floats on the 16-bit MFMA, fp32 accumulate) in the coarse "
+                      "ray-search scans, f32 elsewhere" if split else
+                      "bf16 coarse ray-search scans, f32 elsewhere" if bf16 else "f32"),
             "sdf_evals_per_step": stats, "step": mode}
 
 
@@ -530,7 +568,9 @@ def main():
     ap.add_argument("--calib", default="1,0", help="gather_calib: lanes per 128-B block, byte stride between them")
     ap.add_argument("--bf16", type=int, default=-1,
                     help="1: the ray tracer's coarse scans on the bf16 kernel (default for --cfg C5 = BASELINE configs[4])")
-    ap.add_argument("--only", choices=["gather", "gather_bwd", "mlp", "mlp_bf16", "gemm", "gather_calib"], default=None,
+    ap.add_argument("--split", choices=["bf16x2", "f16x2"], default=None,
+                    help="coarse scans of every leg on the split-operand kernel (default for --cfg C5: bf16x2)")
+    ap.add_argument("--only", choices=["gather", "gather_bwd", "mlp", "mlp_bf16", "mlp_split", "gemm", "gather_calib"], default=None,
                     help="profiling helper: run just one kernel section on cuda:0 and print its object")
     ap.add_argument("--cfg", default=None,
                     help="hash-grid config (tests/golden/params.py): default C2 = BASELINE configs[1] at every --gpus N; "
@@ -565,6 +605,8 @@ def main():
             print(json.dumps(gather_bwd_roofline(emb, args.gather_log2n)))
         elif args.only == "mlp_bf16":
             print(json.dumps(mlp_bf16_roofline(model.implicit_network)))
+        elif args.only == "mlp_split":
+            print(json.dumps(mlp_split_roofline(model.implicit_network, args.split or "f16x2")))
         elif args.only == "gemm":
             print(json.dumps(gemm_roofline(dev)))
         else:
@@ -597,14 +639,16 @@ def main():
         from hashmodnffbanks_idr_amd.training.optim import ClipAdam   # clip_grad_norm_(1.0) + Adam in three launches
         return ClipAdam(model.parameters(), lr=lr, max_norm=1.0)
 
-    use_bf16 = (args.bf16 == 1) or (args.bf16 < 0 and cfg == "C5")
+    use_split = args.split or ("bf16x2" if (cfg == "C5" and args.bf16 < 0) else None)
+    use_bf16 = (args.bf16 == 1) and not use_split
 
-    def run_one(cfg_, lr, sampler_head, steps, warmup, bf16):
+    def run_one(cfg_, lr, sampler_head, steps, warmup, bf16, split=None):
         """one timed leg on ALL ranks (it contains collectives when world > 1)"""
         import types
         a = types.SimpleNamespace(no_graph=args.no_graph, warmup=warmup, steps=steps, rays=args.rays)
         model = _build(cfg_, device, lr)
         model.implicit_network.bf16_coarse_search = bf16
+        model.implicit_network.coarse_split = split
         model.ray_tracer.sampler_head = sampler_head
         reducer = _make_reducer(model, world, args.no_graph)
         torch.manual_seed(100 + rank)  # per-rank eikonal points / step fractions
@@ -623,11 +667,18 @@ def main():
     for leg, lr, sampler_head in (("fixed", 0.0, 0), ("train", 1.0e-4, 0), ("lazy", 0.0, LAZY_SAMPLER_HEAD)):
         if args.legs not in ("both", leg):
             continue
-        legs[leg], model = run_one(cfg, lr, sampler_head, args.steps, args.warmup, use_bf16)
+        legs[leg], model = run_one(cfg, lr, sampler_head, args.steps, args.warmup, use_bf16, split=use_split)
         if leg == "fixed":
             head_model = model
     if "fixed" not in legs:
         head_model = model
+    split_leg = None
+    if not args.no_extras and cfg in ("C2", "C4") and args.legs in ("both", "fixed") and world == 1:
+        # the headline iteration with the coarse scans on the split-operand kernel (fp16 hi + lo, 22-bit operands):
+        # same workload, same evaluation count; reported beside the headline, which stays exact fp32
+        split_leg, _m = run_one(cfg, 0.0, 0, args.steps, args.warmup, False, split="f16x2")
+        split_leg["coarse_scans"] = "f16x2 split operands on v_mfma_f32_32x32x16_f16 (csrc/hm_sdf_split.hip)"
+        del _m
     c4_leg = None
     if not args.no_extras and cfg == "C2" and args.rays == RAYS_PER_GPU:
         # BASELINE configs[3] (T = 2^22; 16 384 rays over 8 GPUs = these 2048 rays per GPU), short fixed-weights leg at
@@ -644,8 +695,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "data": "synthetic",
-            "dtype": "bf16 (ray-search coarse scans on v_mfma_f32_32x32x16_bf16, fp32 accumulate; sphere tracing, secant "
-                     "refinement and every grad-enabled evaluation f32)" if use_bf16 else "f32",
+            "dtype": (f"{use_split} (ray-search coarse scans with hi + lo 16-bit split operands on the 16-bit MFMA, fp32 "
+                      "accumulate; sphere tracing, secant refinement and every grad-enabled evaluation f32)" if use_split else
+                      "bf16 (ray-search coarse scans on v_mfma_f32_32x32x16_bf16, fp32 accumulate; sphere tracing, secant "
+                      "refinement and every grad-enabled evaluation f32)" if use_bf16 else "f32"),
             "config": {"workload": f"DTU-shaped synthetic uniform-sphere rays, "
                                    + (f"{NFFB_CONFIGS[cfg][0]} embedder over a hash grid " if cfg in NFFB_CONFIGS else "MultiResHash ")
                                    + f"L={L} T=2^{T} F=2 "
@@ -676,6 +729,8 @@ def main():
             line["lazy_sampler_leg"] = legs["lazy"]
         if c4_leg is not None:
             line["config4_leg"] = c4_leg
+        if split_leg is not None:
+            line["split_f16x2_leg"] = split_leg
         if not args.no_extras and world > 1:
             # N > 1: the kernel rooflines / CPU baseline are single-GPU measurements and belong to the N = 1 line
             emb = head_model.implicit_network.embed_model.embedder_obj
@@ -697,13 +752,18 @@ def main():
                 line["roofline_c4"] = gather_roofline(emb4, args.gather_log2n)
                 del emb4
             line["roofline_mlp_bf16"] = mlp_bf16_roofline(_build(cfg, device, 0.0).implicit_network)
+            line["roofline_mlp_f16x2"] = mlp_split_roofline(_build(cfg, device, 0.0).implicit_network, "f16x2")
+            line["roofline_mlp_bf16x2"] = mlp_split_roofline(_build(cfg, device, 0.0).implicit_network, "bf16x2")
             line["roofline_gemm"] = gemm_roofline(device)
             line["cpu_baseline"] = cpu_baseline(head_model)
             if world == 1:     # BASELINE configs[2] and [4] (filter-bank embedders), short legs beside the headline
                 # (sampler_head = 16 changes nothing at these networks' initialisation: none of their sampler rays
                 #  has a sign change among the head samples, both passes run in full - 33.0 vs 32.5 ms at C3)
                 line["config3_leg"] = _side_leg("C3", device, False)
-                line["config5_leg"] = _side_leg("C5", device, True)
+                # configs[4] ("bf16"): the coarse scans on bf16 hi + lo operands - plain bf16 operands miss the 2 % loss-curve
+                # criterion on this embedder (tests/test_bf16_gpu.py), the split kind meets it (tests/test_split_gpu.py)
+                line["config5_leg"] = _side_leg("C5", device, False, split="bf16x2")
+                line["config5_leg_plain_bf16"] = _side_leg("C5", device, True)
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -56,6 +56,9 @@ SIGNATURES = {
     "hm_pack_mlp_layer_bf16": (_int, [_p, _i64, _int, _int, _int, _p, _p]),
     "hm_sdf_fwd_bf16": (_int, [_p, _p, _p, _i64, _p, _p, _p, _i64, _int, _p, _i64, _p]),
     "hm_sdf_fwd_emb_bf16": (_int, [_p, _p, _i64, _int, _i64, _p, _i64, _p, _i64, _p]),
+    "hm_pack_mlp_layer_split": (_int, [_p, _i64, _int, _int, _int, C.c_float, C.c_float, _int, _p, _p]),
+    "hm_sdf_fwd_split": (_int, [_p, _p, _p, _i64, _p, _p, _p, _i64, _int, _p, _i64, _p]),
+    "hm_sdf_fwd_emb_split": (_int, [_p, _p, _i64, _int, _i64, _p, _i64, _p, _i64, _p]),
     "hm_pack_mlp_layer": (_int, [_p, _i64, _p, _int, _int, _int, _p, _p, _p, _p]),
     "hm_softplus": (_int, [_int, _p, _p, _p, _p, _p, _i64, C.c_float, C.c_float, _p]),
     "hm_sdf_head": (_int, [_int, _p, _i64, _i64, C.c_float, _p, _p, _p, _p, _p, _p]),
@@ -79,7 +82,7 @@ class MlpLayer(C.Structure):
     _fields_ = [("w_packed", C.c_void_p), ("bias", C.c_void_p), ("out_dim", C.c_int32), ("n_tiles", C.c_int32),
                 ("seg_octets", C.c_int32 * 2), ("seg_src", C.c_int32 * 2), ("activation", C.c_int32),
                 ("post_div_sqrt2", C.c_int32), ("w_packed_m16", C.c_void_p), ("seg_blocks16", C.c_int32 * 2),
-                ("w_packed_bf16", C.c_void_p)]
+                ("w_packed_bf16", C.c_void_p), ("w_packed_split", C.c_void_p)]
 
 
 class GemmEpilogue(C.Structure):
@@ -117,7 +120,7 @@ class NffbDesc(C.Structure):
 
 
 class MlpDesc(C.Structure):
-    _fields_ = [("n_layers", C.c_int32), ("beta", C.c_float), ("layer", MlpLayer * 16)]
+    _fields_ = [("n_layers", C.c_int32), ("beta", C.c_float), ("layer", MlpLayer * 16), ("split_kind", C.c_int32)]
 
 
 class HashmodError(RuntimeError):

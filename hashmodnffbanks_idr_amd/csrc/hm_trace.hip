@@ -581,16 +581,20 @@ static int trace_forward_impl(const hm_grid_desc *desc, const hm_nffb_desc *nffb
             } else {
                 rc = hm_sdf_fwd(desc, mlp, p, capacity, table, B_fourier, v, 1, 1, frac_mode, tile_points, n_dev, 0, stream);
             }
-        } else if (nffb) {   // coarse scans in bf16 above 8192 live points, exact fp32 small tiles below
+        } else if (nffb) {   // coarse scans on the 16-bit matrix cores above 8192 live points, exact fp32 small tiles below
             rc = hm_nffb_fwd(desc, nffb, p, capacity, table, B_fourier, emb_ws, emb_width, frac_mode, n_dev, stream);
             if (rc == HM_OK)
                 rc = hm_sdf_fwd_emb(mlp, emb_ws, emb_width, emb_width, capacity, v, 1, 1, -1, n_dev, 0, stream);
             if (rc == HM_OK)
-                rc = hm_sdf_fwd_emb_bf16(mlp, emb_ws, emb_width, emb_width, capacity, v, 1, n_dev, 8193, stream);
+                rc = cfg->coarse_bf16 == 2
+                         ? hm_sdf_fwd_emb_split(mlp, emb_ws, emb_width, emb_width, capacity, v, 1, n_dev, 8193, stream)
+                         : hm_sdf_fwd_emb_bf16(mlp, emb_ws, emb_width, emb_width, capacity, v, 1, n_dev, 8193, stream);
         } else {
             rc = hm_sdf_fwd(desc, mlp, p, capacity, table, B_fourier, v, 1, 1, frac_mode, -1, n_dev, 0, stream);
             if (rc == HM_OK)
-                rc = hm_sdf_fwd_bf16(desc, mlp, p, capacity, table, B_fourier, v, 1, frac_mode, n_dev, 8193, stream);
+                rc = cfg->coarse_bf16 == 2
+                         ? hm_sdf_fwd_split(desc, mlp, p, capacity, table, B_fourier, v, 1, frac_mode, n_dev, 8193, stream)
+                         : hm_sdf_fwd_bf16(desc, mlp, p, capacity, table, B_fourier, v, 1, frac_mode, n_dev, 8193, stream);
         }
         return rc;
     };

@@ -118,6 +118,17 @@ class ImplicitNetwork(nn.Module):
         # run on the bf16 MFMA variant of the fused kernel; sphere tracing, secant refinement and every grad-enabled
         # evaluation stay exact fp32.  Off by default: the reference has no reduced-precision behaviour.
         self.bf16_coarse_search = False
+        # precision of the same coarse scans on the SPLIT-operand kernel (csrc/hm_sdf_split.hip): None (off), "bf16x2"
+        # (hi + lo bf16 operands, 16 significant bits: the accurate form of the "bf16" configuration) or "f16x2" (hi +
+        # lo fp16, 22 significant bits: error below the rounding noise of an fp32 accumulation).  Takes precedence over
+        # bf16_coarse_search.  Off by default, like it.
+        self.coarse_split = None
+
+    def coarse_mode(self):
+        """hm_trace_cfg.coarse_bf16 value of this network: 0 exact fp32, 1 bf16, 2 split operands"""
+        if self.coarse_split is not None:
+            return 2
+        return 1 if self.bf16_coarse_search else 0
 
     def __getstate__(self):  # the packed-weight cache holds raw device pointers: never copied / pickled
         d = self.__dict__.copy()
@@ -161,7 +172,7 @@ class ImplicitNetwork(nn.Module):
         # _lib.param_epoch(), which is part of the key
         key = (_lib.param_epoch(),) + tuple((p.data_ptr(), p._version) for p in ps)
         if self._packed is None or key != self._packed_key or self._force_repack or \
-                self._packed.has_bf16 != bool(self.bf16_coarse_search):
+                self._packed.has_bf16 != bool(self.bf16_coarse_search) or self._packed.split != self.coarse_split:
             self._force_repack = False
             with torch.no_grad():
                 fc = self._fold_cache or {}      # this forward's folds (made with grad enabled): reuse their values
@@ -172,9 +183,9 @@ class ImplicitNetwork(nn.Module):
                     Ws.append(w.detach() if w is not None else _folded_weight(lin))
                 bs = [getattr(self, "lin" + str(l)).bias for l in range(self.num_layers - 1)]
                 if self._packed is None or self._packed.bufs[0][0].device != Ws[0].device or \
-                        self._packed.has_bf16 != bool(self.bf16_coarse_search):
+                        self._packed.has_bf16 != bool(self.bf16_coarse_search) or self._packed.split != self.coarse_split:
                     self._packed = ops.PackedSdf(Ws, bs, self.dims[0], self.skip_in, self._beta_value(),
-                                                 with_bf16=bool(self.bf16_coarse_search))
+                                                 with_bf16=bool(self.bf16_coarse_search), split=self.coarse_split)
                 else:
                     self._packed.update(Ws, bs, self._beta_value())
             self._packed_key = key

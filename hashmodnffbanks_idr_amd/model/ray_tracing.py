@@ -74,7 +74,8 @@ class RayTracing(nn.Module):
             cfg = _lib.TraceCfg(float(self.object_bounding_sphere), float(self.sdf_threshold),
                                 float(self.line_search_step), int(self.line_step_iters),
                                 int(self.sphere_tracing_iters), int(self.n_steps), int(self.n_secant_steps),
-                                1 if self.training else 0, 1 if getattr(net, "bf16_coarse_search", False) else 0,
+                                1 if self.training else 0,
+                                net.coarse_mode() if hasattr(net, "coarse_mode") else 0,
                                 int(self.sampler_head))
             nf = net._nffb_embedder() if net._hash_embedder() is None else None
             need = ops.trace_workspace_bytes(N, cfg, nf.n_levels if nf is not None else 0)

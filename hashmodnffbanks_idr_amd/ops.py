@@ -490,11 +490,16 @@ class PackedSdf:
     The image buffers are allocated once (stable pointers, so the descriptor stays valid across
     optimizer steps and inside captured graphs); update() re-packs them with one kernel per layer."""
 
-    def __init__(self, weights, biases, E, skip_in, beta, with_bf16=False):
+    def __init__(self, weights, biases, E, skip_in, beta, with_bf16=False, split=None):
         n = len(weights)
         self.has_bf16 = bool(with_bf16)
         self.bf16 = []
+        if split not in (None, "bf16x2", "f16x2"):
+            raise ValueError("hashmod PackedSdf: split must be None, 'bf16x2' or 'f16x2'")
+        self.split = split                  # kind of the (hi, lo) operand images for hm_sdf_fwd_split, or None
+        self.split_imgs, self.split_scales = [], []
         self.desc = _lib.MlpDesc()
+        self.desc.split_kind = {None: -1, "bf16x2": 0, "f16x2": 1}[split]
         self.desc.n_layers = n
         self.keep, self.segs, self.bufs = [], [], []
         dev = weights[0].device
@@ -524,6 +529,15 @@ class PackedSdf:
                 ly.w_packed_bf16 = ib.data_ptr()
             else:
                 ly.w_packed_bf16 = None
+            if split is not None:  # [tile][16-block][hi | lo][64 lanes][8] 2-byte elements (int16 as the container)
+                isp = torch.empty(n_tiles * (b0 + b1) * 1024, dtype=torch.int16, device=dev)
+                self.split_imgs.append(isp)
+                ly.w_packed_split = isp.data_ptr()
+                # the skip layer consumes cat[x, emb]/sqrt(2): x is divided by the previous layer's epilogue, the
+                # embedding segment carries the factor in its weights
+                self.split_scales.append((1.0, 1.0 / math.sqrt(2.0)) if l in skip_in else (1.0, 1.0))
+            else:
+                ly.w_packed_split = None
             ly.out_dim, ly.n_tiles = out_dim, n_tiles
             ly.seg_octets[0], ly.seg_octets[1] = oct0, oct1
             ly.seg_blocks16[0], ly.seg_blocks16[1] = b0, b1
@@ -551,6 +565,10 @@ class PackedSdf:
             if self.has_bf16:
                 check(lib().hm_pack_mlp_layer_bf16(dptr(W), W.stride(0), out_dim, w0, w1, dptr(self.bf16[l]),
                                                    stream_ptr(W)))
+            if self.split is not None:
+                s0, s1 = self.split_scales[l]
+                check(lib().hm_pack_mlp_layer_split(dptr(W), W.stride(0), out_dim, w0, w1, s0, s1, self.desc.split_kind,
+                                                    dptr(self.split_imgs[l]), stream_ptr(W)))
 
 
 def sdf_fwd(desc, packed, x, table, B, frac_mode=0, sdf_only=False, max_workgroups=0, tile_points=0, n_dev=None):
@@ -578,6 +596,33 @@ def sdf_fwd_bf16(desc, packed, x, table, B, frac_mode=0, n_dev=None, run_min=0):
     out = torch.empty((n, 1), dtype=torch.float32, device=x.device)
     check(lib().hm_sdf_fwd_bf16(desc.handle, C.byref(packed.desc), dptr(x), n, dptr(table), dptr(B.contiguous()),
                                 dptr(out), 1, int(frac_mode), dptr(n_dev), int(run_min), stream_ptr(x)))
+    return out[:, 0]
+
+
+def sdf_fwd_split(desc, packed, x, table, B, frac_mode=0, n_dev=None, run_min=0):
+    """sdf-only values [N] from the split-operand kernel (hm_sdf_fwd_split; kind = packed.split)."""
+    x = _prep_x(x)
+    require_gpu(x, table, B)
+    if packed.split is None:
+        raise ValueError("hashmod sdf_fwd_split: the packed weights carry no split image")
+    n = x.shape[0]
+    out = torch.empty((n, 1), dtype=torch.float32, device=x.device)
+    check(lib().hm_sdf_fwd_split(desc.handle, C.byref(packed.desc), dptr(x), n, dptr(table), dptr(B.contiguous()),
+                                 dptr(out), 1, int(frac_mode), dptr(n_dev), int(run_min), stream_ptr(x)))
+    return out[:, 0]
+
+
+def sdf_fwd_emb_split(packed, emb, n_dev=None, run_min=0):
+    """the same on precomputed embedding rows (hm_sdf_fwd_emb_split)"""
+    require_gpu(emb)
+    if packed.split is None:
+        raise ValueError("hashmod sdf_fwd_emb_split: the packed weights carry no split image")
+    if emb.stride(-1) != 1:
+        emb = emb.contiguous()
+    n, width = emb.shape
+    out = torch.empty((n, 1), dtype=torch.float32, device=emb.device)
+    check(lib().hm_sdf_fwd_emb_split(C.byref(packed.desc), dptr(emb), emb.stride(0), width, n, dptr(out), 1,
+                                     dptr(n_dev), int(run_min), stream_ptr(emb)))
     return out[:, 0]
 
 

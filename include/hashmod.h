@@ -195,12 +195,22 @@ typedef struct hm_mlp_layer {
     /* optional bf16 image for hm_sdf_fwd_bf16 (NULL = not provided): same K space as the 16-k image,
      * w_packed_bf16[((u*nb + t)*64 + l)*8 + j] = bf16(W[32u + (l&31)][16t + 8(l>>5) + j]),  u < n_tiles (2-byte elements). */
     const void *w_packed_bf16;
+    /* optional SPLIT image for hm_sdf_fwd_split (NULL = not provided): every weight as a pair (hi, lo) of 2-byte floats of
+     * the kind hm_mlp_desc.split_kind names, W ~= hi + lo * 2^-s (s = 0 for bf16, 11 for fp16), same K space as the 16-k
+     * image:  w_packed_split[(((u*nb + t)*2 + part)*64 + l)*8 + j] = part(c * W[32u + (l&31)][16t + 8(l>>5) + j]),
+     * part 0 = hi, 1 = lo, c = the segment's scale given to hm_pack_mlp_layer_split.                                      */
+    const void *w_packed_split;
 } hm_mlp_layer;
+
+#define HM_SPLIT_NONE (-1)
+#define HM_SPLIT_BF16X2 0 /* hi, lo bf16: 16 significant bits per operand */
+#define HM_SPLIT_F16X2 1  /* hi, lo fp16 (lo scaled by 2^11): 22 significant bits per operand, |v| <= 65504 */
 
 typedef struct hm_mlp_desc {
     int32_t n_layers;
     float beta; /* LaplaceDensity: |beta_param| + beta_min (density_net.py:28-30) */
     hm_mlp_layer layer[HM_MAX_LAYERS];
+    int32_t split_kind; /* kind of the layers' w_packed_split images (HM_SPLIT_*), HM_SPLIT_NONE when absent */
 } hm_mlp_desc;
 
 /* Builds the operand images of one layer from its folded matrix W [out_dim, seg_width0 + seg_width1]
@@ -237,6 +247,26 @@ HM_API int hm_sdf_fwd_bf16(const hm_grid_desc *desc, const hm_mlp_desc *mlp, con
                            const int32_t *n_dev, int64_t run_min, void *stream);
 HM_API int hm_sdf_fwd_emb_bf16(const hm_mlp_desc *mlp, const float *emb, int64_t emb_stride, int emb_width, int64_t n,
                                float *out, int64_t out_stride, const int32_t *n_dev, int64_t run_min, void *stream);
+
+/* Split-operand variant, sdf-only output out[i*out_stride] (csrc/hm_sdf_split.hip): EVERY operand of every matrix product
+ * (weights, hidden activations, embedding) is a (hi, lo) pair of 16-bit floats and W x is evaluated as
+ * Wh xh + 2^-s (Wh xl + Wl xh) on v_mfma_f32_32x32x16_{bf16,f16} with fp32 accumulation - three MFMAs at 16x the fp32
+ * MFMA rate.  HM_SPLIT_BF16X2: relative product error 2^-16 (the "bf16" configuration, BASELINE configs[4], with 250x the
+ * accuracy of plain bf16 operands); HM_SPLIT_F16X2: <= 3 * 2^-22, below the rounding noise of an fp32 accumulation over
+ * K = 512.  Bias, Softplus, the last layer and the clamp are fp32.  Runs only when the live point count is >= run_min
+ * (pair it with hm_sdf_fwd(tile_points = -1) for the small counts).  Needs w_packed, bias and w_packed_split in every
+ * layer and mlp->split_kind.  hm_pack_mlp_layer_split builds one layer's split image (n_tiles*nb*1024 2-byte elements)
+ * from the folded matrix; seg_scale0/1 multiply the two K segments (the skip layer's embedding segment carries the
+ * 1/sqrt(2) of cat[x, emb]/sqrt(2), implicit_differentiable_renderer.py:99-100).  No reference behaviour exists for
+ * these modes: tests/test_split_gpu.py measures them against hm_sdf_fwd and an fp64 evaluation.                        */
+HM_API int hm_pack_mlp_layer_split(const float *W, int64_t ldw, int out_dim, int seg_width0, int seg_width1,
+                                   float seg_scale0, float seg_scale1, int split_kind, void *w_packed_split,
+                                   void *stream);
+HM_API int hm_sdf_fwd_split(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *x, int64_t n,
+                            const float *table, const float *B_fourier, float *out, int64_t out_stride, int frac_mode,
+                            const int32_t *n_dev, int64_t run_min, void *stream);
+HM_API int hm_sdf_fwd_emb_split(const hm_mlp_desc *mlp, const float *emb, int64_t emb_stride, int emb_width, int64_t n,
+                                float *out, int64_t out_stride, const int32_t *n_dev, int64_t run_min, void *stream);
 
 /* The same network evaluated on PRECOMPUTED embedding rows emb[i*emb_stride .. + emb_width) instead of encoding x in
  * the kernel: the SDF network on top of an embedder other than the plain hash grid (FourierFilterBanks via
@@ -296,7 +326,8 @@ typedef struct hm_trace_cfg {
     int32_t n_steps;
     int32_t n_secant_steps;
     int32_t training;
-    int32_t coarse_bf16;           /* != 0: the sampler / closest-approach scans run on hm_sdf_fwd_bf16 (needs w_packed_bf16);
+    int32_t coarse_bf16;           /* precision of the sampler / closest-approach scans: 0 exact fp32, 1 hm_sdf_fwd_bf16 (needs
+                                      w_packed_bf16), 2 hm_sdf_fwd_split (needs w_packed_split; kind = mlp->split_kind);
                                       sphere tracing and the secant refinement stay on the exact-fp32 kernels */
     int32_t sampler_head;          /* lazy sampler.  ray_sampler (ray_tracing.py:189-249) evaluates n_steps samples per
                                       unconverged ray but reads only those up to the FIRST negative one (:212-218, and

@@ -1,0 +1,179 @@
+"""Split-operand kernels (csrc/hm_sdf_split.hip): the fused SDF forward on the 16-bit matrix cores with every operand
+carried as a (hi, lo) pair - "bf16x2" (16 significant bits) and "f16x2" (22 significant bits).  The reference has no
+such mode, so nothing here is a parity claim against it: the tests MEASURE both kinds against the
+exact-fp32 kernel and against an fp64 evaluation of the same network, and apply the loss-curve criterion."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_implicit
+
+pytestmark = pytest.mark.gpu
+
+
+def _c2_net(g, bias=1.0):
+    return make_implicit("C2", (512,) * 8, 256, int(g["seed"]), float(g["perturb"]), float(g["table_scale"]),
+                         bias=float(g["bias"]) if "bias" in g.files else bias)
+
+
+def _mlp_fp64(net, e):
+    """the SDF column of ImplicitNetwork.forward (implicit_differentiable_renderer.py:96-113) in float64 on the fp32
+    embedding rows e: folded weights g v / ||v||, Softplus(100, threshold 20), skip concat / sqrt(2), Laplace clamp"""
+    from hashmodnffbanks_idr_amd.model.implicit_differentiable_renderer import _folded_weight
+    e = e.double()
+    x = e
+    n_lin = net.num_layers - 1
+    for l in range(n_lin):
+        lin = getattr(net, "lin" + str(l))
+        if l in net.skip_in:
+            x = torch.cat([x, e], 1) / np.sqrt(2.0)
+        with torch.no_grad():
+            if hasattr(lin, "weight_g"):
+                v, gg = lin.weight_v.double(), lin.weight_g.double()
+                W = gg * v / v.norm(dim=1, keepdim=True)
+            else:
+                W = lin.weight.double()
+        x = x @ W.t() + lin.bias.double()
+        if l < n_lin - 1:
+            x = torch.where(x * 100.0 > 20.0, x, torch.log1p(torch.exp(torch.clamp(x * 100.0, max=20.0))) / 100.0)
+    s = x[:, 0]
+    beta = net.dencity_net.beta.detach().abs().double() + 1e-4
+    rho = (1.0 / beta) * (0.5 + 0.5 * torch.sign(s) * torch.expm1(-s.abs() / beta))
+    return torch.tanh(s / (2.0 + rho))
+
+
+@pytest.mark.parametrize("kind", ["bf16x2", "f16x2"])
+def test_split_kernel_against_fp32_and_fp64(golden, kind):
+    from hashmodnffbanks_idr_amd import ops
+    g = golden("raytrace_C2")
+    net = _c2_net(g)
+    emb = net._hash_embedder()
+    x = (torch.rand(64 * 300 + 41, 3, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5)) * 2 - 1)
+    with torch.no_grad():
+        ref32 = net.sdf(x)                                   # exact-fp32 MFMA kernel
+        e = ops.encode_fwd(emb.desc, x, emb.table.detach(), emb.freq_encoding.B, 0)
+        ref64 = _mlp_fp64(net, e)
+        net.coarse_split = kind
+        pk = net.packed_weights()
+        assert pk.split == kind
+        got = ops.sdf_fwd_split(emb.desc, pk, x, emb.table.detach(), emb.freq_encoding.B)
+    assert torch.isfinite(got).all()
+    e32 = (ref32.double() - ref64).abs()
+    esp = (got.double() - ref64).abs()
+    d = (got - ref32).abs()
+    print(f"[{kind}] vs fp64 on {x.shape[0]} points: split max |d| {esp.max().item():.3e} mean {esp.mean().item():.3e};  "
+          f"exact-fp32 kernel max |d| {e32.max().item():.3e} mean {e32.mean().item():.3e};  split vs fp32 kernel max "
+          f"{d.max().item():.3e};  sign flips vs fp32 {int(((got < 0) != (ref32 < 0)).sum())}")
+    if kind == "f16x2":
+        # 22-bit operands: within a small factor of the fp32 kernel's own distance from the fp64 value
+        assert esp.max().item() <= max(8 * e32.max().item(), 2e-6)
+        assert esp.mean().item() <= max(4 * e32.mean().item(), 2e-7)
+        assert d.max().item() <= 1e-5                          # the north star's tolerance, against the fp32 kernel
+    else:
+        assert esp.max().item() <= 2e-4 and esp.mean().item() <= 2e-5
+    n_dev = torch.tensor([5000], dtype=torch.int32, device="cuda")
+    with torch.no_grad():
+        part = ops.sdf_fwd_split(emb.desc, pk, x, emb.table.detach(), emb.freq_encoding.B, n_dev=n_dev)
+    assert torch.equal(part[:5000], got[:5000])
+
+
+@pytest.mark.parametrize("kind", ["bf16x2", "f16x2"])
+def test_tracer_with_split_coarse_scans(golden, kind):
+    """device tracer at the bench configuration (2048 rays, training mode): coarse scans on the split kernel vs fp32"""
+    from hashmodnffbanks_idr_amd.model.ray_tracing import RayTracing
+    g = golden("raytrace_C2")
+    net = _c2_net(g)
+    net.eval()
+    outs = []
+    for split in (None, kind):
+        net.coarse_split = split
+        rt = RayTracing(1.0, 5.0e-5, 0.5, 3, 10, 100, 8).cuda()
+        rt.train(True)
+        rt.steps_override = torch.from_numpy(g["steps"])
+        with torch.no_grad():
+            outs.append(rt(sdf=net.sdf, cam_loc=torch.from_numpy(g["cam_loc"]).cuda(),
+                           object_mask=torch.from_numpy(g["object_mask"]).cuda(),
+                           ray_directions=torch.from_numpy(g["ray_dirs"]).cuda()))
+        st = rt.last_stats
+        assert st["unfinished"] == 0 and st["nonfinite"] == 0
+    (p1, m1, d1), (p2, m2, d2) = outs
+    flips = int((m1 != m2).sum())
+    same = (m1 == m2)
+    dd = (d1 - d2).abs()[same]
+    moved = int((dd > 1e-6).sum())
+    print(f"[{kind}] coarse tracer: {flips} / {m1.numel()} mask flips; {moved} rays with |dist| diff > 1e-6, max "
+          f"{dd.max().item():.2e}")
+    assert flips <= (2 if kind == "f16x2" else 0.01 * m1.numel())
+    if kind == "f16x2":
+        assert moved <= 0.01 * m1.numel()
+
+
+def _c5_model(golden):
+    from helpers import make_idr_nffb
+    g = golden("idr_step_C5")
+    return g, make_idr_nffb(str(g["embed_type"]), int(g["seed"]))
+
+
+@pytest.mark.parametrize("kind", ["bf16x2", "f16x2"])
+def test_split_emb_kernel_on_stylemod(golden, kind):
+    """hm_sdf_fwd_emb_split on the embedding rows of the StyleModNFFB network of idr_step_C5.npz (what bench.py's
+    config5_leg runs with kind bf16x2)"""
+    from hashmodnffbanks_idr_amd import ops
+    g, model = _c5_model(golden)
+    net = model.implicit_network
+    n = 64 * 450 + 41
+    x = (torch.rand(n, 3, device="cuda", generator=torch.Generator(device="cuda").manual_seed(12)) * 2 - 1)
+    with torch.no_grad():
+        e = ops.nffb_fwd(net._nffb_embedder(), x)
+        ref32 = ops.sdf_fwd_emb(net.packed_weights(), e, sdf_only=True)
+        ref64 = _mlp_fp64(net, e)
+        net.coarse_split = kind
+        pk = net.packed_weights()
+        got = ops.sdf_fwd_emb_split(pk, e)
+    e32 = (ref32.double() - ref64).abs()
+    esp = (got.double() - ref64).abs()
+    print(f"[{kind}] StyleModNFFB rows vs fp64: split max |d| {esp.max().item():.3e} mean {esp.mean().item():.3e};  "
+          f"exact-fp32 kernel max {e32.max().item():.3e} mean {e32.mean().item():.3e}; sign flips vs fp32 "
+          f"{int(((got < 0) != (ref32 < 0)).sum())}")
+    assert torch.isfinite(got).all()
+    if kind == "f16x2":
+        assert esp.max().item() <= max(8 * e32.max().item(), 2e-6)
+    else:
+        assert esp.max().item() <= 2e-4 and esp.mean().item() <= 2e-5
+
+
+@pytest.mark.parametrize("kind", ["bf16x2"])
+def test_loss_curve_50_steps_split_vs_fp32_on_stylemod(golden, kind):
+    """SURVEY.md 8(d) on the configuration bench.py's config5_leg times: StyleModNFFB, 2048 rays, captured step, 50 steps
+    with lr 1e-4 - 10-step window means of the split-coarse run within 2 % (+ the fp32 run-to-run spread) of fp32"""
+    from hashmodnffbanks_idr_amd.model.loss import IDRLoss
+    from hashmodnffbanks_idr_amd.training.graph_step import GraphedTrainStep
+    from hashmodnffbanks_idr_amd.training.optim import ClipAdam
+    curves = []
+    for split in (None, kind, None):
+        g, model = _c5_model(golden)
+        model.train()
+        model.implicit_network.coarse_split = split
+        inp = {k: torch.from_numpy(g[k]).cuda() for k in ("intrinsics", "uv", "pose", "object_mask")}
+        gt = {"rgb": torch.from_numpy(g["rgb_gt"]).cuda()}
+        loss_fn = IDRLoss(eikonal_weight=0.1, mask_weight=100.0, alpha=50.0)
+        stepper = GraphedTrainStep(model, loss_fn, ClipAdam(model.parameters(), lr=1e-4), warmup=2)
+        torch.manual_seed(9)
+        losses = []
+        for _ in range(50):
+            _, lo = stepper.step(inp, gt)
+            losses.append(lo["loss"].clone())
+        curves.append(torch.stack(losses).cpu().numpy())
+        assert stepper.g_fb is not None
+        st = model.ray_tracer.last_stats
+        assert st["nonfinite"] == 0 and st["unfinished"] == 0
+    a, b, a2 = curves
+    win = lambda c: c.reshape(5, 10).mean(1)          # noqa: E731
+    rel, spread = np.abs(a - b) / np.abs(a), np.abs(a - a2) / np.abs(a)
+    rel_w, spread_w = np.abs(win(a) - win(b)) / win(a), np.abs(win(a) - win(a2)) / win(a)
+    print("fp32 :", [f"{v:.5f}" for v in a[[0, 1, 2, 5, 10, 25, 49]]])
+    print(f"{kind}:", [f"{v:.5f}" for v in b[[0, 1, 2, 5, 10, 25, 49]]])
+    print(f"StyleModNFFB 50-step loss curves fp32 vs {kind}-coarse: per-step max rel diff {rel.max():.3e} (fp32 vs fp32: "
+          f"{spread.max():.3e}); 10-step windows max rel diff {rel_w.max():.3e} (fp32 vs fp32: {spread_w.max():.3e})")
+    assert rel_w.max() <= 0.02 + spread_w.max()
+    assert rel.max() <= 0.02 + 2 * spread.max()
