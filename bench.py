@@ -765,7 +765,7 @@ def main():
                 line["config5_leg"] = _side_leg("C5", device, False, split="bf16x2")
                 line["config5_leg_plain_bf16"] = _side_leg("C5", device, True)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

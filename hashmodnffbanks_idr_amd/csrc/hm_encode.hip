@@ -319,12 +319,19 @@ __device__ __forceinline__ int z_slab(float z) {
     return (int)fminf(fmaxf(t, 0.0f), (float)(kSlabs - 1));
 }
 
-__global__ __launch_bounds__(1024) void zsort_hist_kernel(const float *__restrict__ x, int64_t n, uint32_t *hist) {
+// slab_out (optional, [n] uint16): the slab of every point, so that the scatter pass reads 2 bytes per point instead of
+// striding through x again
+__global__ __launch_bounds__(1024) void zsort_hist_kernel(const float *__restrict__ x, int64_t n, uint32_t *hist,
+                                                          uint16_t *__restrict__ slab_out) {
     __shared__ uint32_t h[kSlabs];
     for (int i = threadIdx.x; i < kSlabs; i += 1024) h[i] = 0u;
     __syncthreads();
     const int64_t beg = (int64_t)blockIdx.x * kSortChunk, end = min(beg + kSortChunk, n);
-    for (int64_t i = beg + threadIdx.x; i < end; i += 1024) atomicAdd(&h[z_slab(x[i * 3 + 2])], 1u);
+    for (int64_t i = beg + threadIdx.x; i < end; i += 1024) {
+        const int sl = z_slab(x[i * 3 + 2]);
+        if (slab_out) slab_out[i] = (uint16_t)sl;
+        atomicAdd(&h[sl], 1u);
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < kSlabs; i += 1024)
         if (h[i]) atomicAdd(&hist[i], h[i]);
@@ -349,12 +356,14 @@ __global__ __launch_bounds__(kSlabs) void zsort_scan_kernel(uint32_t *hist) {
 }
 
 __global__ __launch_bounds__(1024) void zsort_scatter_kernel(const float *__restrict__ x, int64_t n, uint32_t *cursor,
-                                                             uint32_t *__restrict__ order) {
+                                                             uint32_t *__restrict__ order,
+                                                             const uint16_t *__restrict__ slab_in) {
     __shared__ uint32_t h[kSlabs], base[kSlabs];
     for (int i = threadIdx.x; i < kSlabs; i += 1024) h[i] = 0u;
     __syncthreads();
     const int64_t beg = (int64_t)blockIdx.x * kSortChunk, end = min(beg + kSortChunk, n);
-    for (int64_t i = beg + threadIdx.x; i < end; i += 1024) atomicAdd(&h[z_slab(x[i * 3 + 2])], 1u);
+    auto slab_of = [&](int64_t i) { return slab_in ? (int)slab_in[i] : z_slab(x[i * 3 + 2]); };
+    for (int64_t i = beg + threadIdx.x; i < end; i += 1024) atomicAdd(&h[slab_of(i)], 1u);
     __syncthreads();
     for (int i = threadIdx.x; i < kSlabs; i += 1024) {
         base[i] = h[i] ? atomicAdd(&cursor[i], h[i]) : 0u;   // reserve this workgroup's range of the slab
@@ -362,7 +371,7 @@ __global__ __launch_bounds__(1024) void zsort_scatter_kernel(const float *__rest
     }
     __syncthreads();
     for (int64_t i = beg + threadIdx.x; i < end; i += 1024) {
-        const int sl = z_slab(x[i * 3 + 2]);
+        const int sl = slab_of(i);
         order[base[sl] + atomicAdd(&h[sl], 1u)] = (uint32_t)i;
     }
 }
@@ -378,8 +387,9 @@ __global__ __launch_bounds__(kThreadsS) void encode_fwd_f2_zorder_kernel(HmLevel
     const bool fourier = (Bf != nullptr);
     const int hoff = fourier ? 3 + 2 * L : 0;
     const int E = hoff + 2 * L;
-    float *s_out = smem;                                                // [kTileS][E]
-    float *s_x = smem + kTileS * E;                                     // [kTileS][3]
+    const int ES = (E + 3) & ~3;                                        // LDS row stride: rows start on 16-byte boundaries
+    float *s_out = smem;                                                // [kTileS][ES]
+    float *s_x = smem + kTileS * ES;                                    // [kTileS][3]
     uint32_t *s_i = reinterpret_cast<uint32_t *>(s_x + kTileS * 3);     // [kTileS] original row of each point
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -406,11 +416,13 @@ __global__ __launch_bounds__(kThreadsS) void encode_fwd_f2_zorder_kernel(HmLevel
             s_x[i] = (p < cnt) ? x[(int64_t)s_i[p] * 3 + c] : 0.0f;
         }
         __syncthreads();
+        if (ES > E && tid < kTileS)
+            for (int c = E; c < ES; ++c) s_out[tid * ES + c] = 0.0f;
         if (fourier) {
             const int p = tid & (kTileS - 1);
             const int cg = tid / kTileS;  // 0..1
             const float x0 = s_x[p * 3 + 0], x1 = s_x[p * 3 + 1], x2 = s_x[p * 3 + 2];
-            float *o = s_out + p * E;
+            float *o = s_out + p * ES;
             if (cg == 0) {
                 o[0] = x0; o[1] = x1; o[2] = x2;
             }
@@ -459,7 +471,7 @@ __global__ __launch_bounds__(kThreadsS) void encode_fwd_f2_zorder_kernel(HmLevel
                     a0 = dpp_add_xor2(a0); a1 = dpp_add_xor2(a1);
                     a0 = dpp_add_half_mirror(a0); a1 = dpp_add_half_mirror(a1);
                     if (corner == 0) {
-                        float *o = s_out + (wave * 32 + j * 8 + sub) * E + hoff + 2 * lvl[kk];
+                        float *o = s_out + (wave * 32 + j * 8 + sub) * ES + hoff + 2 * lvl[kk];
                         o[0] = a0;
                         o[1] = a1;
                     }
@@ -467,12 +479,26 @@ __global__ __launch_bounds__(kThreadsS) void encode_fwd_f2_zorder_kernel(HmLevel
             }
         }
         __syncthreads();
-        // rows go back to their ORIGINAL positions: half a wave writes one row as contiguous dwords (nt: streamed)
-        {
+        // rows go back to their ORIGINAL positions (nt: streamed).  With a padded row stride (out_stride a multiple of 4
+        // floats >= ES, 16-byte aligned base: ops.encode_fwd allocates big outputs that way) ONE dwordx4 instruction of
+        // ES/4 lanes writes a whole row - the 32-byte sectors of the row leave the CU together instead of as the three
+        // partial-line stores of the dword path (WRITE_SIZE 1.44x the output bytes, profiles/r02_gather_pmc.json)
+        if (((out_stride & 3) == 0) && out_stride >= ES && (reinterpret_cast<uintptr_t>(out) & 15u) == 0) {
+            const int nv = ES >> 2;                       // float4 per row (17 at E = 67)
+            const int rows_per_wave = 64 / nv;            // 3
+            const int g = lane / nv, li = lane - g * nv;
+            if (g < rows_per_wave) {
+                for (int p = wave * rows_per_wave + g; p < cnt; p += (kThreadsS / 64) * rows_per_wave) {
+                    typedef float f32x4v __attribute__((ext_vector_type(4)));
+                    const f32x4v v = *reinterpret_cast<const f32x4v *>(s_out + p * ES + 4 * li);
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4v *>(out + (int64_t)s_i[p] * out_stride) + li);
+                }
+            }
+        } else {
             const int hw = tid >> 5, hl = tid & 31;   // 16 half-waves
             for (int p = hw; p < cnt; p += kThreadsS / 32) {
                 float *dst = out + (int64_t)s_i[p] * out_stride;
-                const float *src = s_out + p * E;
+                const float *src = s_out + p * ES;
                 for (int c = hl; c < E; c += 32) __builtin_nontemporal_store(src[c], dst + c);
             }
         }
@@ -584,10 +610,14 @@ __global__ __launch_bounds__(kThreads) void encode_bwd_table_tracked_kernel(HmLe
                                                                             uint32_t *__restrict__ bits,
                                                                             int32_t *__restrict__ count,
                                                                             int32_t *__restrict__ rows_out, int64_t cap) {
+    // reference weights: only corner 0 of a voxel carries weight (hashGridEmbedding.py:86,94), so a lane per (point,
+    // level) does all there is to do; trilinear weights: a lane per (point, level, corner)
+    constexpr int C = FRAC == HM_FRAC_REFERENCE ? 1 : 8;
+    __shared__ int32_t s_cnt[kThreads / 64], s_base;
     const int L = lv.L, F = lv.F;
     const int64_t gid = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    const int c = (int)(gid & 7);
-    const int64_t pl = gid >> 3;
+    const int c = (int)(gid % C);
+    const int64_t pl = gid / C;
     const int64_t i = pl / L;
     const int l = (int)(pl - i * L);
     bool claimed = false;
@@ -610,14 +640,24 @@ __global__ __launch_bounds__(kThreads) void encode_bwd_table_tracked_kernel(HmLe
             claimed = (atomicOr(bits + (grow >> 5), bit) & bit) == 0u;
         }
     }
+    // slots for the newly claimed rows: ONE atomicAdd on the shared counter per workgroup (a returning atomic per wave
+    // on one address serialises in the L2: 6144 of them cost 40 us of a 65 us launch)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t m = __ballot(claimed);
-    if (m == 0ull) return;
-    const int lane = threadIdx.x & 63;
-    int base = 0;
-    if (lane == (int)__ffsll((long long)m) - 1) base = atomicAdd(count, (int32_t)__popcll(m));
-    base = __shfl(base, (int)__ffsll((long long)m) - 1);
+    if (lane == 0) s_cnt[wave] = (int32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int32_t tot = 0;
+        for (int w = 0; w < kThreads / 64; ++w) {
+            const int32_t v = s_cnt[w];
+            s_cnt[w] = tot;
+            tot += v;
+        }
+        s_base = tot > 0 ? atomicAdd(count, tot) : 0;
+    }
+    __syncthreads();
     if (claimed) {
-        const int64_t slot = (int64_t)base + __popcll(m & ((1ull << lane) - 1ull));
+        const int64_t slot = (int64_t)s_base + s_cnt[wave] + __popcll(m & ((1ull << lane) - 1ull));
         if (slot < cap) rows_out[slot] = (int32_t)grow;     // (slot >= cap: reported by hm_rows_pack through `status`)
     }
 }
@@ -811,9 +851,9 @@ extern "C" {
 
 int64_t hm_encode_bwd_workspace_bytes(const hm_grid_desc *desc, int64_t n) {
     if (!desc || n < 0) return hm_fail(HM_ERR_INVALID, "hm_encode_bwd_workspace_bytes: bad argument");
-    // [slab counters 2*kSlabs u32 | order n u32 | xs 3n f32 | dfs L*F*n f32], each part 256-byte aligned
+    // [slab counters 2*kSlabs u32 | order n u32 | xs 3n f32 | dfs L*F*n f32 | slab ids n u16], each part 256-byte aligned
     auto up = [](int64_t b) { return (b + 255) / 256 * 256; };
-    return up(4 * 2 * kSlabs) + up(4 * n) + up(12 * n) + up(4 * n * desc->lv.L * desc->lv.F);
+    return up(4 * 2 * kSlabs) + up(4 * n) + up(12 * n) + up(4 * n * desc->lv.L * desc->lv.F) + up(2 * n);
 }
 
 int hm_encode_bwd_table_ws(const hm_grid_desc *desc, const float *x, int64_t n, const float *d_feat,
@@ -835,11 +875,14 @@ int hm_encode_bwd_table_ws(const hm_grid_desc *desc, const float *x, int64_t n, 
     uint32_t *order = reinterpret_cast<uint32_t *>(wsb + up(4 * 2 * kSlabs));
     float *xs = reinterpret_cast<float *>(wsb + up(4 * 2 * kSlabs) + up(4 * (size_t)n));
     float *dfs = reinterpret_cast<float *>(wsb + up(4 * 2 * kSlabs) + up(4 * (size_t)n) + up(12 * (size_t)n));
+    uint16_t *slab = reinterpret_cast<uint16_t *>(wsb + up(4 * 2 * kSlabs) + up(4 * (size_t)n) + up(12 * (size_t)n) +
+                                                  up(4 * (size_t)n * lv.L * lv.F));
     hm_zero_u32_async(hist, kSlabs, st);
     const unsigned g_sort = (unsigned)((n + kSortChunk - 1) / kSortChunk);
-    hipLaunchKernelGGL(zsort_hist_kernel, dim3(g_sort), dim3(1024), 0, st, x, n, hist);
+    hipLaunchKernelGGL(zsort_hist_kernel, dim3(g_sort), dim3(1024), 0, st, x, n, hist, slab);
     hipLaunchKernelGGL(zsort_scan_kernel, dim3(1), dim3(kSlabs), 0, st, hist);
-    hipLaunchKernelGGL(zsort_scatter_kernel, dim3(g_sort), dim3(1024), 0, st, x, n, hist, order);
+    hipLaunchKernelGGL(zsort_scatter_kernel, dim3(g_sort), dim3(1024), 0, st, x, n, hist, order,
+                       static_cast<const uint16_t *>(slab));
     hipLaunchKernelGGL(zsort_pack_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, x, d_feat, d_feat_stride,
                        order, n, lv.L * lv.F, xs, dfs);
     static thread_local bool attr_done = false;
@@ -874,7 +917,7 @@ int hm_encode_bwd_table_tracked(const hm_grid_desc *desc, const float *x, int64_
     if (n == 0) return HM_OK;
     HM_CHECK_ARG(x && d_feat && d_table && touched_bits && touched_count && touched_rows,
                  "hm_encode_bwd_table_tracked: NULL pointer");
-    const int64_t threads = n * desc->lv.L * 8;
+    const int64_t threads = n * desc->lv.L * (frac_mode == HM_FRAC_REFERENCE ? 1 : 8);
     const int64_t grid = (threads + kThreads - 1) / kThreads;
     HM_CHECK_ARG(grid <= 0x7fffffffLL, "hm_encode_bwd_table_tracked: n too large for one launch");
     if (frac_mode == HM_FRAC_REFERENCE)
@@ -958,7 +1001,8 @@ int hm_corner_ids(const hm_grid_desc *desc, int level, const float *x, int64_t n
 
 int64_t hm_encode_workspace_bytes(const hm_grid_desc *desc, int64_t n) {
     if (!desc || n < 0) return hm_fail(HM_ERR_INVALID, "hm_encode_workspace_bytes: bad argument");
-    return (int64_t)sizeof(uint32_t) * (n + 2 * kSlabs);
+    // [slab counters 2*kSlabs u32 | order n u32 | slab ids n u16]
+    return (int64_t)sizeof(uint32_t) * (n + 2 * kSlabs) + (int64_t)sizeof(uint16_t) * ((n + 1) & ~(int64_t)1);
 }
 
 static int encode_fwd_impl(const hm_grid_desc *desc, const float *x, int64_t n, const float *table,
@@ -999,7 +1043,7 @@ static int encode_fwd_impl(const hm_grid_desc *desc, const float *x, int64_t n, 
     const size_t lds_sweep = sizeof(float) * (size_t)(kTileS * width + kTileS * 3);
     const bool table_exceeds_l2 = desc->total_rows * (uint64_t)lv.F * 4u > (8u << 20);   // (C1's 0.9 MiB: tile kernel)
     static const int zorder_cfg = [] { const char *e = getenv("HM_ENCODE_ZORDER"); return e ? atoi(e) : 1; }();
-    const size_t lds_z = sizeof(float) * (size_t)(kTileS * width + kTileS * 3 + kTileS);
+    const size_t lds_z = sizeof(float) * (size_t)(kTileS * ((width + 3) & ~3) + kTileS * 3 + kTileS);
     if (lv.F == 2 && zorder_cfg != 0 && workspace && table_exceeds_l2 && n >= (int64_t)131072 && n < ((int64_t)1 << 32) &&
         lds_z <= 160 * 1024 && workspace_bytes >= (int64_t)sizeof(uint32_t) * (n + 2 * kSlabs)) {
         static thread_local bool attr_z = false;
@@ -1015,11 +1059,16 @@ static int encode_fwd_impl(const hm_grid_desc *desc, const float *x, int64_t n, 
         hipStream_t st = as_stream(stream);
         uint32_t *hist = static_cast<uint32_t *>(workspace);        // [kSlabs] counts -> start offsets -> cursors
         uint32_t *order = hist + 2 * kSlabs;                          // [n]
+        // [n] uint16 slab ids behind the order array when the caller's workspace has room for them (older, smaller
+        // workspaces still work: the scatter pass then recomputes the slabs from x)
+        uint16_t *slab = workspace_bytes >= hm_encode_workspace_bytes(desc, n) ? reinterpret_cast<uint16_t *>(order + n)
+                                                                             : nullptr;
         hm_zero_u32_async(hist, kSlabs, st);
         const unsigned g_sort = (unsigned)((n + kSortChunk - 1) / kSortChunk);
-        hipLaunchKernelGGL(zsort_hist_kernel, dim3(g_sort), dim3(1024), 0, st, x, n, hist);
+        hipLaunchKernelGGL(zsort_hist_kernel, dim3(g_sort), dim3(1024), 0, st, x, n, hist, slab);
         hipLaunchKernelGGL(zsort_scan_kernel, dim3(1), dim3(kSlabs), 0, st, hist);
-        hipLaunchKernelGGL(zsort_scatter_kernel, dim3(g_sort), dim3(1024), 0, st, x, n, hist, order);
+        hipLaunchKernelGGL(zsort_scatter_kernel, dim3(g_sort), dim3(1024), 0, st, x, n, hist, order,
+                           static_cast<const uint16_t *>(slab));
         const int64_t tiles = (n + kTileS - 1) / kTileS;
         static const int z_grid = [] { const char *e = getenv("HM_ENCODE_ZGRID"); return e ? atoi(e) : 512; }();
         const unsigned grid = (unsigned)(tiles < z_grid ? ((tiles + 7) / 8) * 8 : z_grid);

@@ -88,16 +88,21 @@ def encode_fwd(desc, x, table, B, frac_mode=0, hash_only=False):
     assert table.is_contiguous() and table.dtype == torch.float32 and table.shape == (desc.total_rows, desc.F)
     n = x.shape[0]
     width = desc.L * desc.F if hash_only else desc.E
-    out = torch.empty((n, width), dtype=torch.float32, device=x.device)
     Bp = None if hash_only else B.contiguous()
     if n >= 131072:     # big launches: z-ordered gather (needs scratch for the point permutation)
+        # rows padded to a multiple of 4 floats (268 -> 272 bytes at E = 67): every row then starts on a 16-byte boundary
+        # and leaves the kernel as ONE dwordx4 store instruction; the caller gets the [n, width] view of the buffer
+        stride = (width + 3) & ~3
+        buf = torch.empty((n, stride), dtype=torch.float32, device=x.device)
+        out = buf[:, :width] if stride != width else buf
         need = check(lib().hm_encode_workspace_bytes(desc.handle, n))
         ws = _ENC_WS.get(x.device)
         if ws is None or ws.numel() < need:
             ws = _ENC_WS[x.device] = torch.empty(need, dtype=torch.uint8, device=x.device)
-        check(lib().hm_encode_fwd_ws(desc.handle, dptr(x), n, dptr(table), dptr(Bp), dptr(out), width, int(frac_mode),
+        check(lib().hm_encode_fwd_ws(desc.handle, dptr(x), n, dptr(table), dptr(Bp), dptr(buf), stride, int(frac_mode),
                                      dptr(ws), ws.numel(), stream_ptr(x)))
     else:
+        out = torch.empty((n, width), dtype=torch.float32, device=x.device)
         check(lib().hm_encode_fwd(desc.handle, dptr(x), n, dptr(table), dptr(Bp), dptr(out), width, int(frac_mode),
                                   stream_ptr(x)))
     return out

@@ -91,7 +91,10 @@ HM_API int hm_encode_fwd(const hm_grid_desc *desc, const float *x, int64_t n, co
  * (n >= 131072 over tables larger than 8 MiB) then bucket the points by z first and gather in that order: the
  * reference hash puts every (x, y) corner of one z-plane into one 16-KB window of a level's table, so z-ordered
  * points share their table lines on every level (out[i] is still the embedding of x[i]; only the order of the
- * work changes).  Without a workspace (or for small launches) the call is identical to hm_encode_fwd.          */
+ * work changes).  Without a workspace (or for small launches) the call is identical to hm_encode_fwd.
+ * Padded rows: with out_stride a multiple of 4 floats >= ceil(E/4)*4 (272 bytes at E = 67) and a 16-byte aligned `out`
+ * every row leaves the z-ordered kernel as ONE dwordx4 store instruction (the pad floats of a row are written as zeros);
+ * any other stride takes the dword path.                                                                          */
 HM_API int64_t hm_encode_workspace_bytes(const hm_grid_desc *desc, int64_t n);
 HM_API int hm_encode_fwd_ws(const hm_grid_desc *desc, const float *x, int64_t n, const float *table,
                      const float *B_fourier, float *out, int64_t out_stride, int frac_mode, void *workspace,
