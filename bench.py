@@ -155,7 +155,7 @@ def gather_roofline(emb, log2_n=22, iters=10, warmup=3):
     # PMC counters cannot be read from inside this process: the number comes from the separate
     # rocprofv3 --pmc passes of `bench.py --only gather [--cfg C4]` recorded under profiles/ (same kernel, same launch)
     tag = {5217937: "C2", 29295887: "C4"}.get(int(emb.table.shape[0]))
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         name = f"{rnd}_gather_pmc.json" if tag == "C2" else f"{rnd}_gather_{tag}_pmc.json"
         pmc = os.path.join(ROOT, "profiles", name)
         if tag and os.path.exists(pmc) and log2_n == 22 and emb.n_levels == 16:
@@ -171,7 +171,7 @@ def gather_roofline(emb, log2_n=22, iters=10, warmup=3):
             "min_launch_ms": round(float(ms.min()), 4),
             "note": f"table {emb.table.numel() * 4 / 2**20:.1f} MiB (< 256 MiB Infinity Cache); big launches walk the points "
                     "in z order, so the corner rows are served by the L2s: `traffic` (fabric bytes, PMC) is below the "
-                    "algorithmic bytes"}
+                    "algorithmic bytes; output rows are stored at a 272-byte stride (268 algorithmic bytes per row)"}
 
 
 def gather_bwd_roofline(emb, log2_n=22, iters=10, warmup=3, frac_mode=0):
