@@ -1,8 +1,42 @@
 """Shared builders for tests: product modules loaded with the seeded parameters of tests/golden/params.py."""
+import json
+import os
+
 import numpy as np
 import torch
 
 import params as P
+
+# ---- pinned observed errors ---------------------------------------------------------------------------------------
+# Every gradient / step comparison prints its observed error AND asserts it against the value recorded on the MI355X
+# box in the round the test was (last) calibrated: tests/golden/tolerances.json holds the recorded maxima, a test fails
+# when it observes more than 3x the recorded value (floor: the north star's 1e-5 / 2 for relative errors, so that
+# last-bit noise of a quantity recorded at 1e-8 cannot trip it).  A regression of 10x therefore no longer hides under the
+# fixed 1e-4 ... 5e-3 bounds that stay in the tests as outer limits.  HM_RECORD_TOL=<file>: record instead of assert
+# (the file accumulates the maximum per name; scripts/r3f.sh shows the calibration run).
+_TOL_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tolerances.json")
+_TOL = None
+
+
+def pin(name, observed, floor=5e-6, factor=3.0):
+    global _TOL
+    observed = float(observed)
+    rec_path = os.environ.get("HM_RECORD_TOL")
+    if rec_path:
+        data = json.load(open(rec_path)) if os.path.exists(rec_path) else {}
+        data[name] = max(float(data.get(name, 0.0)), observed)
+        os.makedirs(os.path.dirname(os.path.abspath(rec_path)), exist_ok=True)
+        json.dump(data, open(rec_path, "w"), indent=0, sort_keys=True)
+        print(f"    [pin] {name}: observed {observed:.3e} (recorded)")
+        return
+    if _TOL is None:
+        _TOL = json.load(open(_TOL_PATH)) if os.path.exists(_TOL_PATH) else {}
+    if name not in _TOL:
+        print(f"    [pin] {name}: observed {observed:.3e} (no recorded value - run the calibration)")
+        return
+    limit = max(factor * float(_TOL[name]), floor)
+    print(f"    [pin] {name}: observed {observed:.3e}, recorded {float(_TOL[name]):.3e}, limit {limit:.3e}")
+    assert observed <= limit, f"{name}: observed {observed:.3e} > {factor:g} x recorded {float(_TOL[name]):.3e} (floor {floor:g})"
 
 
 class Conf(dict):

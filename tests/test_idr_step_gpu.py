@@ -39,14 +39,20 @@ def _check_first_step(g, out, lo, gn, model, n_rays, tag, max_flips=2):
     assert mism <= max_flips, f"{mism} network_object_mask mismatches"
     keep = ~flip
     per_ray = mism / float(n_rays)
+    from helpers import pin
+    pkey = "step:" + tag.replace(" ", "_")
     for k, share in (("loss", 8.0), ("rgb_loss", 4.0), ("eikonal_loss", 2.0), ("mask_loss", 8.0)):
         ref = float(g[f"s0:{k}"])
         rel = abs(lo[k].item() - ref) / (abs(ref) + 1e-12)
         print(f"    {k}: {lo[k].item():.7g} vs {ref:.7g}  rel {rel:.2e}")
         assert abs(lo[k].item() - ref) <= (2e-4 + share * per_ray) * abs(ref) + 1e-6, (k, lo[k].item(), ref)
+        if mism == 0:      # (a ray on the other side of a tracing threshold moves the sums it enters: not pinned then)
+            pin(f"{pkey}:{k}_rel", rel)
     ref_gn = float(g["s0:total_grad_norm"])
     print(f"    total grad norm: {gn:.6g} vs {ref_gn:.6g}  rel {abs(gn - ref_gn) / ref_gn:.2e}")
     assert abs(gn - ref_gn) <= (2e-3 + 8.0 * per_ray) * ref_gn, (gn, ref_gn)
+    if mism == 0:
+        pin(f"{pkey}:total_grad_norm_rel", abs(gn - ref_gn) / ref_gn, floor=2e-5)
     n_eik = n_rays // 2
     keep_g = np.concatenate([np.ones(n_eik, bool), keep])      # grad_theta rows: eikonal samples, then the ray points
     # (1 % outliers allowed on the per-ray SDF: 0.2 - 0.54 % of the ray points of the T = 2^19 / 2^22 grids sit close
@@ -84,6 +90,8 @@ def _check_first_step(g, out, lo, gn, model, n_rays, tag, max_flips=2):
             worst = max(worst, abs(got - ref) / (ref + 1e-30))
             assert abs(got - ref) <= gtol * ref + 1e-9, (name, got, ref)
     print(f"    per-parameter gradient norms: worst rel {worst:.2e} (tolerance {gtol:.1e})")
+    if mism == 0:
+        pin(f"{pkey}:param_grad_norm_worst_rel", worst, floor=5e-5)
     return mism
 
 

@@ -25,18 +25,28 @@ def test_embedder_forward_backward(golden, tag, et, L):
     np.testing.assert_allclose(y.detach().cpu().numpy(), g["out"], rtol=1e-4, atol=2e-5)
     (y * torch.from_numpy(g["R"]).cuda()).sum().backward()
     np.testing.assert_allclose(x.grad.cpu().numpy(), g["dx"], rtol=1e-3, atol=1e-3 * np.abs(g["dx"]).max())
+    from helpers import pin
+    pin(f"nffb:{tag}_L{L}:out_abs", float(np.abs(y.detach().cpu().numpy() - g["out"]).max()), floor=2e-6)
+    pin(f"nffb:{tag}_L{L}:dx_rel_to_scale", float(np.abs(x.grad.cpu().numpy() - g["dx"]).max() / np.abs(g["dx"]).max()),
+        floor=2e-5)
     eo = emb.embedder_obj.grid_enc
     off = eo.desc.row_off
+    worst = 0.0
     for k, p in emb.named_parameters():
         if k.endswith("grid_enc.table"):
             for l in range(L):
                 ref = float(g[f"gn:embedder_obj.grid_enc.levels.{l}.embedding.weight"])
                 got = p.grad[int(off[l]):int(off[l + 1])].double().norm().item()
                 assert abs(got - ref) <= 1e-3 * ref + 1e-7, (k, l, got, ref)
+                if ref > 1e-6:
+                    worst = max(worst, abs(got - ref) / ref)
         else:
             ref = float(g["gn:" + k])
             got = 0.0 if p.grad is None else p.grad.double().norm().item()
             assert abs(got - ref) <= 1e-3 * ref + 1e-6, (k, got, ref)
+            if ref > 1e-6:
+                worst = max(worst, abs(got - ref) / ref)
+    pin(f"nffb:{tag}_L{L}:param_grad_norm_worst_rel", worst, floor=2e-5)
 
 
 @pytest.mark.parametrize("tag,et", [("ffb", "FFB"), ("stylemod", "StyleModNFFB")])
@@ -88,7 +98,12 @@ def test_sdf_network_on_nffb(golden, tag, et):
                                atol=1e-3 * np.abs(g["gradient"]).max())
     eik = ((gr[:, 0, :].norm(2, dim=1) - 1) ** 2).mean()
     assert abs(eik.item() - float(g["eik"])) <= 1e-3 * float(g["eik"])
+    from helpers import pin
+    pin(f"nffb_sdf:{tag}:gradient_rel_to_scale",
+        float(np.abs(gr.detach().cpu().numpy()[:, 0] - g["gradient"]).max() / np.abs(g["gradient"]).max()), floor=2e-5)
+    pin(f"nffb_sdf:{tag}:eikonal_rel", abs(eik.item() - float(g["eik"])) / float(g["eik"]), floor=2e-5)
     eik.backward()
+    worst = 0.0
     for k, p in net.named_parameters():
         if k.endswith("table"):
             continue
@@ -98,6 +113,9 @@ def test_sdf_network_on_nffb(golden, tag, et):
             continue
         got = p.grad.double().norm().item()
         assert abs(got - ref) <= 5e-3 * ref + 1e-6, (k, got, ref)
+        if ref > 1e-6:
+            worst = max(worst, abs(got - ref) / ref)
+    pin(f"nffb_sdf:{tag}:g2_param_grad_norm_worst_rel", worst, floor=5e-5)
 
 
 @pytest.mark.parametrize("tag,et", [("ffb", "FFB"), ("stylemod", "StyleModNFFB")])

@@ -105,36 +105,46 @@ def test_grad_path_forward_and_first_order(golden, tag, cfg):
     # d/dx sums ~257 signed terms: tolerance relative to the gradient's scale, not per element
     _close(x.grad.cpu().numpy(), g["dx_first"], rtol=2e-5, atol=1e-5 * float(np.abs(g["dx_first"]).max()),
            what="d/dx")
-    _check_param_grads(net, g, "g1")
+    _check_param_grads(net, g, "g1", pin_name=f"sdf:{tag}:g1")
 
 
-def _check_param_grads(net, g, label):
+def _check_param_grads(net, g, label, pin_name=None):
+    """every parameter gradient against the reference's (norms; full tensors or sampled entries); the worst observed
+    errors over all parameters are pinned (helpers.pin: <= 3x the value recorded on the GPU box)"""
+    from helpers import pin
     emb = net.embed_model.embedder_obj
     off = emb.desc.row_off
+    worst = [0.0, 0.0]
     for name, p in net.named_parameters():
         if p.grad is None:
             continue
         arr = p.grad.detach().cpu().numpy()
         if name.endswith("embedder_obj.table"):
             for l in range(emb.n_levels):
-                _cmp(arr[int(off[l]):int(off[l + 1])], g, f"{label}:table{l}")
+                _cmp(arr[int(off[l]):int(off[l + 1])], g, f"{label}:table{l}", worst)
         else:
-            _cmp(arr, g, f"{label}:{name}")
+            _cmp(arr, g, f"{label}:{name}", worst)
+    print(f"    {label}: worst gradient-norm rel error {worst[0]:.3e}, worst entry error / tensor scale {worst[1]:.3e}")
+    if pin_name:
+        pin(pin_name + ":grad_norm_rel", worst[0])
+        pin(pin_name + ":grad_entry_rel_to_scale", worst[1])
 
 
-def _cmp(arr, g, key):
+def _cmp(arr, g, key, worst=None):
     ref_norm = float(g[key + ":norm"])
     got_norm = float(np.linalg.norm(arr.astype(np.float64)))
     assert abs(got_norm - ref_norm) <= 1e-4 * max(ref_norm, 1e-12) + 1e-9, (key, got_norm, ref_norm)
     scale = max(ref_norm / np.sqrt(arr.size), 1e-12)
     if key + ":full" in g.files:
         ref = g[key + ":full"]
-        np.testing.assert_allclose(arr, ref, rtol=1e-4, atol=2e-4 * max(np.abs(ref).max(), scale), err_msg=key)
+        got = arr
     else:
-        idx = g[key + ":idx"]
         ref = g[key + ":val"]
-        np.testing.assert_allclose(arr.reshape(-1)[idx], ref, rtol=1e-4, atol=2e-4 * max(np.abs(ref).max(), scale),
-                                   err_msg=key)
+        got = arr.reshape(-1)[g[key + ":idx"]]
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=2e-4 * max(np.abs(ref).max(), scale), err_msg=key)
+    if worst is not None:
+        worst[0] = max(worst[0], abs(got_norm - ref_norm) / max(ref_norm, 1e-12))
+        worst[1] = max(worst[1], float(np.abs(got - ref).max()) / max(float(np.abs(ref).max()), scale))
 
 
 @pytest.mark.parametrize("tag,cfg", CASES)
@@ -148,8 +158,12 @@ def test_gradient_and_eikonal_double_backward(golden, tag, cfg):
     _close(gr.detach().cpu().numpy()[:, 0, :], g["gradient"], rtol=2e-5, atol=1e-5, what="gradient()")
     eik = ((gr[:, 0, :].norm(2, dim=1) - 1) ** 2).mean()
     assert abs(eik.item() - float(g["eik"])) <= 1e-5 * abs(float(g["eik"])) + 1e-7
+    from helpers import pin
+    pin(f"sdf:{tag}:gradient_rel_to_scale",
+        float(np.abs(gr.detach().cpu().numpy()[:, 0, :] - g["gradient"]).max() / np.abs(g["gradient"]).max()))
+    pin(f"sdf:{tag}:eikonal_rel", abs(eik.item() - float(g["eik"])) / abs(float(g["eik"])))
     eik.backward()
-    _check_param_grads(net, g, "g2")
+    _check_param_grads(net, g, "g2", pin_name=f"sdf:{tag}:g2")
 
 
 def test_gemm_shapes_vs_torch():
