@@ -3,16 +3,16 @@
 // Same operator as hm_sdf.hip's sdf_fwd_kernel (reference: model/implicit_differentiable_renderer.py:89-113 under
 // no_grad; density_net.py:20-30), sdf-only output, for the coarse scans of the ray tracer (model/ray_tracing.py:189-249,
 // 270-298).  Every operand of every matrix product - weights, hidden activations AND the embedding - is carried as a
-// pair (hi, lo) of 16-bit floats with  v ~= hi + lo * 2^-s  and the product is evaluated as
-//         W x  ~=  Wh xh  +  2^-s (Wh xl + Wl xh)                 (three MFMAs, fp32 accumulate; Wl xl is dropped)
+// pair (hi, lo) of 16-bit floats with  c v ~= hi + lo  (c = a power-of-two operand scale) and the product is evaluated as
+//         W x  ~=  (Wh xh + Wh xl + Wl xh) / (c_w c_x)            (three MFMAs, fp32 accumulate; Wl xl is dropped)
 // on v_mfma_f32_32x32x16_{bf16,f16}, which run at 16x the rate of the fp32 MFMA:
 //   HM_SPLIT_BF16X2  hi, lo bf16 (s = 0): 16 significant bits per operand, relative error 2^-16 per product - the
 //                    "bf16" configuration of BASELINE configs[4] with 250x the accuracy of plain bf16 operands;
-//   HM_SPLIT_F16X2   hi, lo fp16 (s = 11, the lo parts are stored scaled by 2^11 so that they stay normal numbers and
-//                    accumulate in a second accumulator set): 22 significant bits per operand, relative error <= 3 * 2^-22
-//                    per product - below the rounding noise an fp32 accumulation over K = 512 adds anyway
-//                    (~ sqrt(K) 2^-24); values beyond the fp16 range (|v| > 65504) become non-finite and are counted by
-//                    the tracer's non-finite counter.
+//   HM_SPLIT_F16X2   hi, lo fp16; activations are stored scaled by 2^4 and weights by 2^8 (so that the lo parts of
+//                    ordinary magnitudes are normal fp16 numbers; smaller ones are subnormals, which the MFMA keeps):
+//                    22 significant bits per operand, relative error <= 3 * 2^-22 per product - below the rounding noise
+//                    an fp32 accumulation over K = 512 adds anyway (~ sqrt(K) 2^-24); activations beyond |x| = 4094
+//                    become non-finite and are counted by the tracer's non-finite counter.
 // The reference has no such mode; tests/test_split_gpu.py measures both kinds against the exact-fp32 kernel and against
 // an fp64 evaluation, and applies SURVEY.md 8(d)'s loss-curve criterion.
 //
@@ -42,8 +42,7 @@ template <> struct Split<HM_SPLIT_BF16X2> {
     typedef __bf16 T;
     typedef bf16x8 V8;
     typedef bf16x4 V4;
-    static constexpr float up = 1.0f, down = 1.0f;
-    static constexpr int sets = 1;      // lo products go into the same accumulators
+    static constexpr float xs = 1.0f, ws = 1.0f, inv = 1.0f;   // operand scales (bf16 has fp32's exponent range: none)
     static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
@@ -52,18 +51,22 @@ template <> struct Split<HM_SPLIT_F16X2> {
     typedef _Float16 T;
     typedef f16x8 V8;
     typedef f16x4 V4;
-    static constexpr float up = 2048.0f, down = 1.0f / 2048.0f;
-    static constexpr int sets = 2;      // lo products (scaled by 2^11) accumulate apart and are folded in at the end
+    // fp16 lo parts are ~2^-11 of their value: activations are stored scaled by 2^4 and weights by 2^8 so that the lo
+    // parts of ordinary magnitudes (|x| >= 0.008, |w| >= 5e-4) are NORMAL fp16 numbers; smaller ones become subnormal,
+    // which the MFMA keeps (scripts/f16_denorm_probe.hip) - their absolute error stays below 2^-25 / scale.  The
+    // accumulators hold 2^12 x the sums; `inv` is applied together with the bias.  Range: |x| <= 4094, |w| <= 255.
+    static constexpr float xs = 16.0f, ws = 256.0f, inv = 1.0f / 4096.0f;
     static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
     }
 };
 
+// v (already multiplied by the operand's scale) -> hi + lo
 template <int KIND>
 __device__ __forceinline__ void split_val(float v, typename Split<KIND>::T &hi, typename Split<KIND>::T &lo) {
     typedef typename Split<KIND>::T T;
     hi = (T)v;                                              // round to nearest even
-    lo = (T)(__fsub_rn(v, (float)hi) * Split<KIND>::up);
+    lo = (T)__fsub_rn(v, (float)hi);
 }
 
 constexpr int kPS = 64;            // points per workgroup tile
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(kTS, 2) void sdf_fwd_split_kernel(HmLevels lv, SdfN
 
     auto put = [&](int p, int e, float v) {
         T hi, lo;
-        split_val<KIND>(v, hi, lo);
+        split_val<KIND>(v * S::xs, hi, lo);
         const size_t o = (size_t)(e >> 3) * kOctE + p * 8 + (e & 7);
         EH[o] = hi;
         EL[o] = lo;
@@ -172,6 +175,31 @@ __global__ __launch_bounds__(kTS, 2) void sdf_fwd_split_kernel(HmLevels lv, SdfN
         __syncthreads();
 
         // ---------------- layers ------------------------------------------------------------------------------
+        // weight ring: D slots per image part, D-1 blocks in flight (fp16 kind: two accumulator sets leave room for
+        // three slots only - a fourth spills).  It lives across the layers: the first D-1 blocks of layer l+1 are
+        // requested before layer l's epilogue (weights do not depend on the activations), so the stream does not
+        // restart from an empty pipe behind the two barriers of every layer.
+        constexpr int D = 4;
+        FragS<KIND> r0h[D], r0l[D], r1h[D], r1l[D];
+        bool ring_ready = false;
+        auto ring_fill = [&](const float4 *A0, const float4 *A1, int nbs) {
+#pragma unroll
+            for (int st = 0; st < D - 1; ++st) {
+                const size_t off = (size_t)min(st, nbs - 1) * 128;
+                r0h[st].f = A0[off]; r0l[st].f = A0[off + 64];
+                r1h[st].f = A1[off]; r1l[st].f = A1[off + 64];
+            }
+        };
+        auto prefetch_layer = [&](int l) {      // segment 0 of layer l, this wave's feature tiles
+            const hm_mlp_layer &Lp = net.layer[l];
+            const int ntp = max(0, min(2, Lp.n_tiles - 2 * wave));
+            if (ntp <= 0) return false;
+            const int nbp = Lp.seg_blocks16[0] + Lp.seg_blocks16[1];
+            const float4 *P0 = reinterpret_cast<const float4 *>(Lp.w_packed_split) + ((size_t)(2 * wave) * nbp) * 128 + lane;
+            const float4 *P1 = P0 + (ntp > 1 ? (size_t)nbp * 128 : 0);
+            ring_fill(P0, P1, Lp.seg_blocks16[0]);
+            return true;
+        };
         for (int li = 0; li < net.n_layers; ++li) {
             const hm_mlp_layer &Ly = net.layer[li];
             if (li == net.n_layers - 1) {
@@ -188,7 +216,7 @@ __global__ __launch_bounds__(kTS, 2) void sdf_fwd_split_kernel(HmLevels lv, SdfN
                     const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
-                        part = __fmaf_rn(__fmaf_rn((float)xl[e], S::down, (float)xh[e]), wv[e], part);
+                        part = __fmaf_rn(((float)xl[e] + (float)xh[e]) * (1.0f / S::xs), wv[e], part);
                 }
                 RED[sl * kPS + p] = part;
                 __syncthreads();
@@ -202,14 +230,11 @@ __global__ __launch_bounds__(kTS, 2) void sdf_fwd_split_kernel(HmLevels lv, SdfN
             const int nt = Ly.n_tiles;
             const int t0 = 2 * wave;
             const int ntw = max(0, min(2, nt - t0));
-            f32x16 acc[S::sets][2][2];
+            f32x16 acc[2][2];
 #pragma unroll
-            for (int s = 0; s < S::sets; ++s)
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) acc[s][a][q] = f32x16{0};
-            constexpr int LO = S::sets - 1;
+                for (int q = 0; q < 2; ++q) acc[a][q] = f32x16{0};
             if (ntw > 0) {
                 const int nb = Ly.seg_blocks16[0] + Ly.seg_blocks16[1];
                 int blk0 = 0;
@@ -222,16 +247,8 @@ __global__ __launch_bounds__(kTS, 2) void sdf_fwd_split_kernel(HmLevels lv, SdfN
                     const float4 *A0 = reinterpret_cast<const float4 *>(Ly.w_packed_split) +
                                        ((size_t)t0 * nb + blk0) * 128 + lane;
                     const float4 *A1 = A0 + (ntw > 1 ? (size_t)nb * 128 : 0);
-                    // weight ring: D slots per image part, D-1 blocks in flight (fp16 kind: two accumulator sets leave room
-                    // for three slots only - a fourth spills)
-                    constexpr int D = S::sets == 2 ? 3 : 4;
-                    FragS<KIND> r0h[D], r0l[D], r1h[D], r1l[D];
-#pragma unroll
-                    for (int st = 0; st < D - 1; ++st) {
-                        const size_t off = (size_t)min(st, nbs - 1) * 128;
-                        r0h[st].f = A0[off]; r0l[st].f = A0[off + 64];
-                        r1h[st].f = A1[off]; r1l[st].f = A1[off + 64];
-                    }
+                    if (!(seg == 0 && ring_ready)) ring_fill(A0, A1, nbs);
+                    ring_ready = false;
                     auto block = [&](int t, const FragS<KIND> &a0h, const FragS<KIND> &a0l, const FragS<KIND> &a1h,
                                      const FragS<KIND> &a1l) {
                         const size_t o = (size_t)(2 * t + h) * kOctE + j * 8;
@@ -240,18 +257,18 @@ __global__ __launch_bounds__(kTS, 2) void sdf_fwd_split_kernel(HmLevels lv, SdfN
                         const V8 bl0 = *reinterpret_cast<const V8 *>(srcL + o);
                         const V8 bl1 = *reinterpret_cast<const V8 *>(srcL + o + 32 * 8);
                         // hi x hi, then hi x lo, then lo x hi: accumulators that are used twice are four MFMAs apart
-                        acc[0][0][0] = S::mfma(a0h.h, bh0, acc[0][0][0]);
-                        acc[0][0][1] = S::mfma(a0h.h, bh1, acc[0][0][1]);
-                        acc[0][1][0] = S::mfma(a1h.h, bh0, acc[0][1][0]);
-                        acc[0][1][1] = S::mfma(a1h.h, bh1, acc[0][1][1]);
-                        acc[LO][0][0] = S::mfma(a0h.h, bl0, acc[LO][0][0]);
-                        acc[LO][0][1] = S::mfma(a0h.h, bl1, acc[LO][0][1]);
-                        acc[LO][1][0] = S::mfma(a1h.h, bl0, acc[LO][1][0]);
-                        acc[LO][1][1] = S::mfma(a1h.h, bl1, acc[LO][1][1]);
-                        acc[LO][0][0] = S::mfma(a0l.h, bh0, acc[LO][0][0]);
-                        acc[LO][0][1] = S::mfma(a0l.h, bh1, acc[LO][0][1]);
-                        acc[LO][1][0] = S::mfma(a1l.h, bh0, acc[LO][1][0]);
-                        acc[LO][1][1] = S::mfma(a1l.h, bh1, acc[LO][1][1]);
+                        acc[0][0] = S::mfma(a0h.h, bh0, acc[0][0]);
+                        acc[0][1] = S::mfma(a0h.h, bh1, acc[0][1]);
+                        acc[1][0] = S::mfma(a1h.h, bh0, acc[1][0]);
+                        acc[1][1] = S::mfma(a1h.h, bh1, acc[1][1]);
+                        acc[0][0] = S::mfma(a0h.h, bl0, acc[0][0]);
+                        acc[0][1] = S::mfma(a0h.h, bl1, acc[0][1]);
+                        acc[1][0] = S::mfma(a1h.h, bl0, acc[1][0]);
+                        acc[1][1] = S::mfma(a1h.h, bl1, acc[1][1]);
+                        acc[0][0] = S::mfma(a0l.h, bh0, acc[0][0]);
+                        acc[0][1] = S::mfma(a0l.h, bh1, acc[0][1]);
+                        acc[1][0] = S::mfma(a1l.h, bh0, acc[1][0]);
+                        acc[1][1] = S::mfma(a1l.h, bh1, acc[1][1]);
                     };
                     const int n_full = nbs - nbs % D;
                     for (int tt = 0; tt < n_full; tt += D) {
@@ -273,6 +290,7 @@ __global__ __launch_bounds__(kTS, 2) void sdf_fwd_split_kernel(HmLevels lv, SdfN
                     blk0 += nbs;
                 }
             }
+            if (li + 1 < net.n_layers - 1) ring_ready = prefetch_layer(li + 1);
             __syncthreads();  // every wave has finished reading the planes for this layer
 
             // epilogue: registers 4q..4q+3 of a tile = features 8q + 4h + {0..3} -> 4 elements of one k-octet of the next layer
@@ -291,12 +309,9 @@ __global__ __launch_bounds__(kTS, 2) void sdf_fwd_split_kernel(HmLevels lv, SdfN
                         const float4 bb = *reinterpret_cast<const float4 *>(Ly.bias + f);
                         float v[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float s = acc[0][a][pt][4 * q + e];
-                            if (S::sets == 2) s = __fmaf_rn(acc[LO][a][pt][4 * q + e], S::down, s);
-                            v[e] = s;
-                        }
-                        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                        for (int e = 0; e < 4; ++e) v[e] = acc[a][pt][4 * q + e];
+                        v[0] = __fmaf_rn(v[0], S::inv, bb.x); v[1] = __fmaf_rn(v[1], S::inv, bb.y);
+                        v[2] = __fmaf_rn(v[2], S::inv, bb.z); v[3] = __fmaf_rn(v[3], S::inv, bb.w);
                         V4 oh, ol;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -304,7 +319,7 @@ __global__ __launch_bounds__(kTS, 2) void sdf_fwd_split_kernel(HmLevels lv, SdfN
                             if (act) u = softplus100(u);
                             if (div) u = __fdiv_rn(u, sqrt2);
                             T hi, lo;
-                            split_val<KIND>(u, hi, lo);
+                            split_val<KIND>(u * S::xs, hi, lo);
                             oh[e] = hi;
                             ol[e] = lo;
                         }
@@ -348,7 +363,7 @@ __global__ __launch_bounds__(256) void pack_layer_split_kernel(PackSplitArgs a, 
     }
     const float w = (row < a.out_dim && col >= 0) ? __fmul_rn(a.W[(int64_t)row * a.ldw + col], sc) : 0.0f;
     typename Split<KIND>::T hi, lo;
-    split_val<KIND>(w, hi, lo);
+    split_val<KIND>(w * Split<KIND>::ws, hi, lo);
     const int64_t o = (blk * 2) * 512 + l * 8 + jj;
     img[o] = hi;
     img[o + 512] = lo;

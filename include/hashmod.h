@@ -199,15 +199,15 @@ typedef struct hm_mlp_layer {
      * w_packed_bf16[((u*nb + t)*64 + l)*8 + j] = bf16(W[32u + (l&31)][16t + 8(l>>5) + j]),  u < n_tiles (2-byte elements). */
     const void *w_packed_bf16;
     /* optional SPLIT image for hm_sdf_fwd_split (NULL = not provided): every weight as a pair (hi, lo) of 2-byte floats of
-     * the kind hm_mlp_desc.split_kind names, W ~= hi + lo * 2^-s (s = 0 for bf16, 11 for fp16), same K space as the 16-k
-     * image:  w_packed_split[(((u*nb + t)*2 + part)*64 + l)*8 + j] = part(c * W[32u + (l&31)][16t + 8(l>>5) + j]),
+     * the kind hm_mlp_desc.split_kind names, c_w W ~= hi + lo (c_w = 1 for bf16, 2^8 for fp16), same K space as the 16-k
+     * image:  w_packed_split[(((u*nb + t)*2 + part)*64 + l)*8 + j] = part(c_w c * W[32u + (l&31)][16t + 8(l>>5) + j]),
      * part 0 = hi, 1 = lo, c = the segment's scale given to hm_pack_mlp_layer_split.                                      */
     const void *w_packed_split;
 } hm_mlp_layer;
 
 #define HM_SPLIT_NONE (-1)
 #define HM_SPLIT_BF16X2 0 /* hi, lo bf16: 16 significant bits per operand */
-#define HM_SPLIT_F16X2 1  /* hi, lo fp16 (lo scaled by 2^11): 22 significant bits per operand, |v| <= 65504 */
+#define HM_SPLIT_F16X2 1  /* hi, lo fp16 (activations scaled by 2^4, weights by 2^8): 22 significant bits, |x| <= 4094 */
 
 typedef struct hm_mlp_desc {
     int32_t n_layers;
@@ -253,7 +253,7 @@ HM_API int hm_sdf_fwd_emb_bf16(const hm_mlp_desc *mlp, const float *emb, int64_t
 
 /* Split-operand variant, sdf-only output out[i*out_stride] (csrc/hm_sdf_split.hip): EVERY operand of every matrix product
  * (weights, hidden activations, embedding) is a (hi, lo) pair of 16-bit floats and W x is evaluated as
- * Wh xh + 2^-s (Wh xl + Wl xh) on v_mfma_f32_32x32x16_{bf16,f16} with fp32 accumulation - three MFMAs at 16x the fp32
+ * Wh xh + Wh xl + Wl xh on v_mfma_f32_32x32x16_{bf16,f16} with fp32 accumulation - three MFMAs at 16x the fp32
  * MFMA rate.  HM_SPLIT_BF16X2: relative product error 2^-16 (the "bf16" configuration, BASELINE configs[4], with 250x the
  * accuracy of plain bf16 operands); HM_SPLIT_F16X2: <= 3 * 2^-22, below the rounding noise of an fp32 accumulation over
  * K = 512.  Bias, Softplus, the last layer and the clamp are fp32.  Runs only when the live point count is >= run_min
