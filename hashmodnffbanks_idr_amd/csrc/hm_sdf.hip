@@ -245,7 +245,7 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_kernel(HmLevels lv, Sd
                     float v0 = acc[4 * q + 0] + bb.x, v1 = acc[4 * q + 1] + bb.y, v2 = acc[4 * q + 2] + bb.z,
                           v3 = acc[4 * q + 3] + bb.w;
                     if (act) {
-                        v0 = softplus100(v0); v1 = softplus100(v1); v2 = softplus100(v2); v3 = softplus100(v3);
+                        softplus100_4(v0, v1, v2, v3);
                     }
                     if (div) {
                         v0 = __fdiv_rn(v0, sqrt2); v1 = __fdiv_rn(v1, sqrt2); v2 = __fdiv_rn(v2, sqrt2);
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(kThreads32, 2) void sdf_fwd_p32_kernel(HmLevels lv,
                     float v0 = acc[4 * q + 0] + bb.x, v1 = acc[4 * q + 1] + bb.y, v2 = acc[4 * q + 2] + bb.z,
                           v3 = acc[4 * q + 3] + bb.w;
                     if (act) {
-                        v0 = softplus100(v0); v1 = softplus100(v1); v2 = softplus100(v2); v3 = softplus100(v3);
+                        softplus100_4(v0, v1, v2, v3);
                     }
                     if (div) {
                         v0 = __fdiv_rn(v0, sqrt2); v1 = __fdiv_rn(v1, sqrt2); v2 = __fdiv_rn(v2, sqrt2);
@@ -725,7 +725,7 @@ __device__ __forceinline__ void sdf_m16_body(const HmLevels &lv, const SdfNet &n
                 const float4 bb = *reinterpret_cast<const float4 *>(Ly.bias + f);
                 float v0 = acc[a][0] + bb.x, v1 = acc[a][1] + bb.y, v2 = acc[a][2] + bb.z, v3 = acc[a][3] + bb.w;
                 if (act) {
-                    v0 = softplus100(v0); v1 = softplus100(v1); v2 = softplus100(v2); v3 = softplus100(v3);
+                    softplus100_4(v0, v1, v2, v3);
                 }
                 if (div) {
                     v0 = __fdiv_rn(v0, sqrt2); v1 = __fdiv_rn(v1, sqrt2); v2 = __fdiv_rn(v2, sqrt2);
@@ -988,11 +988,13 @@ __device__ __forceinline__ void sdf_m8_body(const HmLevels &lv, const SdfNet &ne
                 const float4 bb = *reinterpret_cast<const float4 *>(Ly.bias + f);
                 float v[8] = {r0[0] + bb.x, r0[1] + bb.y, r0[2] + bb.z, r0[3] + bb.w,
                               r1[0] + bb.x, r1[1] + bb.y, r1[2] + bb.z, r1[3] + bb.w};
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    if (act) v[i] = softplus100(v[i]);
-                    if (div) v[i] = __fdiv_rn(v[i], sqrt2);
+                if (act) {
+                    softplus100_4(v[0], v[1], v[2], v[3]);
+                    softplus100_4(v[4], v[5], v[6], v[7]);
                 }
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (div) v[i] = __fdiv_rn(v[i], sqrt2);
                 float *dst = X + (f >> 2) * kGroupFloats8;
                 *reinterpret_cast<float4 *>(dst + p4 * 4) = make_float4(v[0], v[1], v[2], v[3]);
                 if (TWO) *reinterpret_cast<float4 *>(dst + (p4 + 4) * 4) = make_float4(v[4], v[5], v[6], v[7]);

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(kTB16, 2) void sdf_fwd_bf16_kernel(HmLevels lv, Sdf
                         float v0 = acc[a][pt][4 * q + 0] + bb.x, v1 = acc[a][pt][4 * q + 1] + bb.y,
                               v2 = acc[a][pt][4 * q + 2] + bb.z, v3 = acc[a][pt][4 * q + 3] + bb.w;
                         if (act) {
-                            v0 = softplus100(v0); v1 = softplus100(v1); v2 = softplus100(v2); v3 = softplus100(v3);
+                            softplus100_4(v0, v1, v2, v3);
                         }
                         if (div) {
                             v0 = __fdiv_rn(v0, sqrt2); v1 = __fdiv_rn(v1, sqrt2); v2 = __fdiv_rn(v2, sqrt2);

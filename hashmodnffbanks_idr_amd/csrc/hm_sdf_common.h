@@ -37,6 +37,27 @@ __device__ __forceinline__ float softplus100(float a) {
     return z > 20.0f ? a : sp;
 }
 
+// Four activations at once on the packed fp32 VALU ops (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: two lanes' worth per
+// issue slot): 6.5 instead of 11 instructions per activation.  The epilogue is VALU work that cannot overlap the MFMAs
+// (in-place activations, workgroup barriers): in the split-operand kernel it costs as many SIMD cycles as the matrix
+// products themselves (profiles/r03_split_mfma_pmc.json), in the fp32 kernel ~19 %.  The threshold select of the scalar
+// form is dropped: for 100 a > 20 the logarithm term is < 2.1e-11 < half an ulp of a >= 0.2, so max(a, 0) + l == a bit
+// for bit - the value nn.Softplus(100, threshold=20) returns.
+typedef float f32x2p __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2p softplus100_x2(f32x2p a) {
+    const f32x2p na = {-fabsf(a.x), -fabsf(a.y)};
+    const f32x2p arg = na * 144.26950408889634f;                       // -|100 a| log2(e)
+    f32x2p t = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+    t = t + 1.0f;
+    const f32x2p lg = {__builtin_amdgcn_logf(t.x), __builtin_amdgcn_logf(t.y)};
+    const f32x2p mx = {fmaxf(a.x, 0.0f), fmaxf(a.y, 0.0f)};
+    return __builtin_elementwise_fma(lg, (f32x2p){0.006931471805599453f, 0.006931471805599453f}, mx);   // ln 2 / 100
+}
+__device__ __forceinline__ void softplus100_4(float &v0, float &v1, float &v2, float &v3) {
+    const f32x2p a = softplus100_x2((f32x2p){v0, v1}), b = softplus100_x2((f32x2p){v2, v3});
+    v0 = a.x; v1 = a.y; v2 = b.x; v3 = b.y;
+}
+
 // density_net.py:20-30 + implicit_differentiable_renderer.py:112
 __device__ __forceinline__ float sdf_clamp(float s, float beta) {
     const float alpha = 1.0f / beta;

@@ -313,10 +313,10 @@ __global__ __launch_bounds__(kTS, 2) void sdf_fwd_split_kernel(HmLevels lv, SdfN
                         v[0] = __fmaf_rn(v[0], S::inv, bb.x); v[1] = __fmaf_rn(v[1], S::inv, bb.y);
                         v[2] = __fmaf_rn(v[2], S::inv, bb.z); v[3] = __fmaf_rn(v[3], S::inv, bb.w);
                         V4 oh, ol;
+                        if (act) softplus100_4(v[0], v[1], v[2], v[3]);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             float u = v[e];
-                            if (act) u = softplus100(u);
                             if (div) u = __fdiv_rn(u, sqrt2);
                             T hi, lo;
                             split_val<KIND>(u * S::xs, hi, lo);
