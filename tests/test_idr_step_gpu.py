@@ -46,13 +46,16 @@ def _check_first_step(g, out, lo, gn, model, n_rays, tag, max_flips=2):
         rel = abs(lo[k].item() - ref) / (abs(ref) + 1e-12)
         print(f"    {k}: {lo[k].item():.7g} vs {ref:.7g}  rel {rel:.2e}")
         assert abs(lo[k].item() - ref) <= (2e-4 + share * per_ray) * abs(ref) + 1e-6, (k, lo[k].item(), ref)
-        if mism == 0:      # (a ray on the other side of a tracing threshold moves the sums it enters: not pinned then)
-            pin(f"{pkey}:{k}_rel", rel)
+        # (a ray on the other side of a tracing threshold moves the sums it enters: not pinned then.  Floors: the step's
+        #  inputs are the tracer's hit points, and the hash features are piecewise constant in them - a last-bit change of
+        #  the no-grad SDF kernel moves a few points across voxel faces and these sums by ~1e-5 relative)
+        if mism == 0:
+            pin(f"{pkey}:{k}_rel", rel, floor=3e-5)
     ref_gn = float(g["s0:total_grad_norm"])
     print(f"    total grad norm: {gn:.6g} vs {ref_gn:.6g}  rel {abs(gn - ref_gn) / ref_gn:.2e}")
     assert abs(gn - ref_gn) <= (2e-3 + 8.0 * per_ray) * ref_gn, (gn, ref_gn)
     if mism == 0:
-        pin(f"{pkey}:total_grad_norm_rel", abs(gn - ref_gn) / ref_gn, floor=2e-5)
+        pin(f"{pkey}:total_grad_norm_rel", abs(gn - ref_gn) / ref_gn, floor=1e-4)
     n_eik = n_rays // 2
     keep_g = np.concatenate([np.ones(n_eik, bool), keep])      # grad_theta rows: eikonal samples, then the ray points
     # (1 % outliers allowed on the per-ray SDF: 0.2 - 0.54 % of the ray points of the T = 2^19 / 2^22 grids sit close
@@ -91,7 +94,7 @@ def _check_first_step(g, out, lo, gn, model, n_rays, tag, max_flips=2):
             assert abs(got - ref) <= gtol * ref + 1e-9, (name, got, ref)
     print(f"    per-parameter gradient norms: worst rel {worst:.2e} (tolerance {gtol:.1e})")
     if mism == 0:
-        pin(f"{pkey}:param_grad_norm_worst_rel", worst, floor=5e-5)
+        pin(f"{pkey}:param_grad_norm_worst_rel", worst, floor=2e-4)
     return mism
 
 
