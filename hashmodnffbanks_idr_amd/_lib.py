@@ -73,6 +73,7 @@ SIGNATURES = {
     "hm_rows_apply": (_int, [_p, _i64, _int, _p, _i64, _i64, _int, C.c_float, _p]),
     "hm_rows_clear": (_int, [_p, _i64, _int, _p, _i64, _i64, _int, _p, _p]),
     "hm_multi_copy_f32": (_int, [_p, _int, _p]),
+    "hm_gemm_f32_group_tn": (_int, [_p, _int, _p]),
     "hm_gemm_f32_ep": (_int, [_int, _int, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _p]),
     "hm_gemm_f32": (_int, [_int, _int, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _int, _p]),
 }
@@ -95,6 +96,11 @@ class GemmEpilogue(C.Structure):
 class AdamTensor(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
                 ("step", C.c_void_p), ("numel", C.c_int64)]
+
+
+class GemmGroupItem(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("M", C.c_int64), ("N", C.c_int64),
+                ("K", C.c_int64), ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64)]
 
 
 class CopyItem(C.Structure):

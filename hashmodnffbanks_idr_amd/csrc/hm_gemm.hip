@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(GemmArgs g) {
 // Same pipeline with EIGHT waves: two wave groups split the octets of every stage (two waves per SIMD hide each
 // other's barrier / LDS turnarounds), partial tiles are summed through LDS at the end.
 template <bool AKC, bool BKC, bool EP>
-__global__ __launch_bounds__(512, 4) void gemm_f32_pipe2_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_pipe2_body(const GemmArgs &g, int bx, int by, int bz) {
     constexpr int BM = 64, BN = 64, BK = kPipeBK, NT = 512, PER = BM * BK / 4 / NT, KG = BK / 4, OCT = BK / 8 / 2;   // OCT: octets of a stage per wave group
     __shared__ __align__(16) float As[2][BK * BM];
     __shared__ __align__(16) float Bs[2][BK * BN];
@@ -397,8 +397,8 @@ __global__ __launch_bounds__(512, 4) void gemm_f32_pipe2_kernel(GemmArgs g) {
     const int kpart = wave >> 2, wsub = wave & 3;   // two wave groups split the octets of every stage
     const int wm = wsub >> 1, wn = wsub & 1;
     const int j = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int kbeg = blockIdx.z * g.k_chunk;
+    const int m0 = bx * BM, n0 = by * BN;
+    const int kbeg = bz * g.k_chunk;
     const int stages = g.k_chunk / BK;   // multiple of kPipeD (host)
 
     const float *pa[PER], *pb[PER];
@@ -472,7 +472,48 @@ __global__ __launch_bounds__(512, 4) void gemm_f32_pipe2_kernel(GemmArgs g) {
         for (int r = 0; r < 16; ++r) acc[r] += red[(wsub * 16 + r) * 64 + lane];
     }
     const int n = n0 + wn * 32 + j;
-    if (n < g.N) gemm_store_tile<EP>(g, acc, n, m0 + wm * 32 + 4 * h, (g.bias != nullptr) && (blockIdx.z == 0));
+    if (n < g.N) gemm_store_tile<EP>(g, acc, n, m0 + wm * 32 + 4 * h, (g.bias != nullptr) && (bz == 0));
+}
+
+template <bool AKC, bool BKC, bool EP>
+__global__ __launch_bounds__(512, 4) void gemm_f32_pipe2_kernel(GemmArgs g) {
+    gemm_pipe2_body<AKC, BKC, EP>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Grouped form for the weight gradients of one backward pass: C_p += A_p^T B_p for up to HM_GEMM_GROUP_MAX problems in ONE
+// launch (A_p [K_p, M_p], B_p [K_p, N_p] row-major: both operands row-contiguous, the shape of  dW = [u; z-bar]^T [v-bar; a]).
+// Launched one by one these GEMMs are 64 tiles each and need an 8-way split-K (and a zeroing launch) to fill the chip
+// at all: 33 - 45 us per layer for 14 - 20 us of matrix work.  Here every (problem, tile, k part) is a workgroup of
+// the same grid: ~1000 of them, four resident per CU, so that one problem's tail overlaps the next one's head.
+struct GemmGroupEntry {
+    const float *A, *B;
+    float *C;
+    int64_t lda, ldb, ldc;
+    int32_t M, N, k_chunk, tiles_m, tiles_n, split;
+};
+struct GemmGroupTable {
+    GemmGroupEntry e[HM_GEMM_GROUP_MAX];
+    int32_t start[HM_GEMM_GROUP_MAX + 1];
+    int32_t n;
+};
+__global__ __launch_bounds__(512, 4) void gemm_f32_pipe2_group_kernel(GemmGroupTable t) {
+    int p = 0;
+    while (p + 1 < t.n && (int)blockIdx.x >= t.start[p + 1]) ++p;       // (uniform: <= 16 problems)
+    const GemmGroupEntry &E = t.e[p];
+    int local = (int)blockIdx.x - t.start[p];
+    const int bz = local % E.split;
+    local /= E.split;
+    const int by = local % E.tiles_n, bx = local / E.tiles_n;
+    GemmArgs g;
+    g.A = E.A; g.B = E.B; g.bias = nullptr; g.C = E.C;
+    g.M = E.M; g.N = E.N; g.K = 0;
+    g.transA = 1; g.transB = 0;
+    g.lda = E.lda; g.ldb = E.ldb; g.ldc = E.ldc;
+    g.k_chunk = E.k_chunk;
+    g.atomic = 1;
+    g.vecA = g.vecB = 0;
+    g.ep.mode = HM_EPI_NONE;
+    gemm_pipe2_body<false, false, false>(g, bx, by, bz);
 }
 
 // zero an M x N window of C (split-K accumulates with atomics); a plain kernel instead of
@@ -633,6 +674,55 @@ int hm_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const f
                 const float *B, int64_t ldb, const float *bias, float *C, int64_t ldc, int accumulate,
                 void *stream) {
     return gemm_impl(transA, transB, M, N, K, A, lda, B, ldb, bias, C, ldc, accumulate, nullptr, stream);
+}
+
+int hm_gemm_f32_group_tn(const hm_gemm_group_item *items, int n_items, void *stream) {
+    HM_CHECK_ARG(n_items >= 0 && (n_items == 0 || items), "hm_gemm_f32_group_tn: bad argument");
+    GemmGroupTable t;
+    t.n = 0;
+    t.start[0] = 0;
+    auto flush = [&]() -> int {
+        if (t.n > 0) {
+            hipLaunchKernelGGL(gemm_f32_pipe2_group_kernel, dim3((unsigned)t.start[t.n]), dim3(512), 0, as_stream(stream), t);
+            HM_CHECK_LAUNCH("hm_gemm_f32_group_tn");
+        }
+        t.n = 0;
+        t.start[0] = 0;
+        return HM_OK;
+    };
+    for (int i = 0; i < n_items; ++i) {
+        const hm_gemm_group_item &it = items[i];
+        HM_CHECK_ARG(it.M >= 0 && it.N >= 0 && it.K >= 0 && it.M < (1ll << 31) && it.N < (1ll << 31) && it.K < (1ll << 31),
+                     "hm_gemm_f32_group_tn: bad dimension");
+        if (it.M == 0 || it.N == 0 || it.K == 0) continue;
+        HM_CHECK_ARG(it.A && it.B && it.C && it.lda >= it.M && it.ldb >= it.N && it.ldc >= it.N,
+                     "hm_gemm_f32_group_tn: NULL operand or leading dimension");
+        if (it.K % (kPipeBK * kPipeD) != 0) {     // no K tail in the pipelined kernel: such a problem goes alone
+            const int rc = gemm_impl(1, 0, it.M, it.N, it.K, it.A, it.lda, it.B, it.ldb, nullptr, it.C, it.ldc, 1, nullptr, stream);
+            if (rc != HM_OK) return rc;
+            continue;
+        }
+        if (t.n == HM_GEMM_GROUP_MAX) {
+            const int rc = flush();
+            if (rc != HM_OK) return rc;
+        }
+        GemmGroupEntry &E = t.e[t.n];
+        E.A = it.A; E.B = it.B; E.C = it.C;
+        E.lda = it.lda; E.ldb = it.ldb; E.ldc = it.ldc;
+        E.M = (int32_t)it.M; E.N = (int32_t)it.N;
+        E.tiles_m = (int32_t)((it.M + 63) / 64);
+        E.tiles_n = (int32_t)((it.N + 63) / 64);
+        // k parts of >= 1024 (eight 128-deep groups) that divide K
+        int64_t split = it.K / 1024;
+        if (split < 1) split = 1;
+        if (split > 4) split = 4;
+        while (split > 1 && (it.K % split != 0 || (it.K / split) % (kPipeBK * kPipeD) != 0)) --split;
+        E.split = (int32_t)split;
+        E.k_chunk = (int32_t)(it.K / split);
+        t.start[t.n + 1] = t.start[t.n] + E.tiles_m * E.tiles_n * E.split;
+        ++t.n;
+    }
+    return flush();
 }
 
 int hm_gemm_f32_ep(int transA, int transB, int64_t M, int64_t N, int64_t K, const float *A, int64_t lda,

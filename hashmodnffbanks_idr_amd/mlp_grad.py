@@ -24,7 +24,7 @@ import torch
 
 from . import ops
 from .ops import (EPI_ADJOINT, EPI_RELU, EPI_RELUMASK, EPI_S1MUL, EPI_SOFTPLUS, _softplus_call, colsum_into, gemm,
-                  gemm_ep)
+                  gemm_ep, gemm_group_tn)
 
 _SQRT2 = math.sqrt(2.0)
 
@@ -149,14 +149,17 @@ class _SdfMlp(torch.autograd.Function):
                         gemm(c.view(N, 1), vb, None, True, False, out=dW[l][0:1], accumulate=True)
 
         # ---- backward of the forward sweep (walks the layers downwards) ------------------------------------
+        # the weight gradients are independent of one another and of the rest of the sweep: they are collected and run as
+        # ONE grouped launch at the end (hm_gemm_f32_group_tn) instead of one split-K GEMM (+ its share of launches) per layer
         zb = ops.sdf_head_bwd(d_out, sdf, c, denom, cb)
         de = None
+        wgrad = []
         for l in range(L - 1, -1, -1):
             if need_w[l]:
                 if ustack[l] is not None:                        # zb IS ustack[l][N:] (written by layer l+1 below)
-                    gemm(ustack[l], stack[l], None, True, False, out=dW[l], accumulate=True)   # [u; z-bar]^T [v-bar; a]
+                    wgrad.append((ustack[l], stack[l], dW[l]))                                  # [u; z-bar]^T [v-bar; a]
                 else:
-                    gemm(zb, a_list[l], None, True, False, out=dW[l], accumulate=True)
+                    wgrad.append((zb, a_list[l], dW[l]))
             if need_b[l]:
                 colsum_into(zb, db[l])
             if l > 0:
@@ -172,6 +175,7 @@ class _SdfMlp(torch.autograd.Function):
             else:
                 ab = gemm(zb, Ws[l], None, False, False)
                 de = ab if de is None else de + ab
+        gemm_group_tn(wgrad)
         d_e = de if ctx.needs_input_grad[0] else None
         return (d_e, None, None, None, None, *dW, *db)
 
@@ -217,15 +221,17 @@ class _ReluMlp(torch.autograd.Function):
             torch._foreach_zero_(zero_list)
         zb = d_y.contiguous()
         dx = None
+        wgrad = []
         for l in range(L - 1, -1, -1):
             if need_w[l]:
-                gemm(zb, acts[l], None, True, False, out=dW[l], accumulate=True)
+                wgrad.append((zb, acts[l], dW[l]))
             if need_b[l]:
                 colsum_into(zb, db[l])
             if l > 0:     # h-bar_l = z-bar_l W_l, masked by relu'(z_{l-1}) = (h_l > 0)
                 zb = gemm_ep(zb, Ws[l], None, False, False, EPI_RELUMASK, 0.0, 0.0, z=acts[l], want_c=False)[1]
             elif ctx.needs_input_grad[0]:
                 dx = gemm(zb, Ws[0], None, False, False)
+        gemm_group_tn(wgrad)
         return (dx, *dW, *db)
 
 

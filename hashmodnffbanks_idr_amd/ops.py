@@ -326,6 +326,27 @@ def gemm(a, b, bias=None, trans_a=False, trans_b=False, out=None, accumulate=Fal
     return out
 
 
+def gemm_group_tn(problems):
+    """C += A^T @ B for every (A [K, M], B [K, N], C [M, N]) of `problems` in ONE launch (hm_gemm_f32_group_tn): the
+    weight gradients of one backward pass.  Row-major fp32 views with arbitrary row strides; C is accumulated into."""
+    if not problems:
+        return
+    items = (_lib.GemmGroupItem * len(problems))()
+    keep = []
+    for i, (a, b, c) in enumerate(problems):
+        require_gpu(a, b, c)
+        a, b = _rowmajor(a), _rowmajor(b)
+        if c.stride(-1) != 1 or a.dtype != torch.float32 or b.dtype != torch.float32 or c.dtype != torch.float32:
+            raise ValueError("hashmod gemm_group_tn: fp32 row-major operands expected")
+        K, M = a.shape
+        Kb, N = b.shape
+        if K != Kb or tuple(c.shape) != (M, N):
+            raise ValueError(f"hashmod gemm_group_tn: shapes {tuple(a.shape)}^T @ {tuple(b.shape)} -> {tuple(c.shape)}")
+        keep += [a, b]
+        items[i] = _lib.GemmGroupItem(a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, _ld(a), _ld(b), _ld(c))
+    check(lib().hm_gemm_f32_group_tn(C.cast(items, C.c_void_p), len(problems), stream_ptr(problems[0][0])))
+
+
 EPI_SOFTPLUS, EPI_S1MUL, EPI_ADJOINT, EPI_RELU, EPI_RELUMASK = 1, 2, 3, 4, 5
 
 

@@ -492,6 +492,19 @@ HM_API int64_t hm_adam_scratch_floats(const hm_adam_tensor *tensors, int n_tenso
 HM_API int hm_adam_step(const hm_adam_tensor *tensors, int n_tensors, float lr, float beta1, float beta2, float eps,
                         float max_norm, float *scratch_dev, void *stream);
 
+/* Weight gradients of one backward pass in ONE launch: C_p += A_p^T B_p for every item (A_p [K, M] and B_p [K, N]
+ * row-major with leading dimensions, C_p [M, N] accumulated with fp32 atomics - the caller zeroes it, like the
+ * reference's optimizer.zero_grad()).  Replaces the per-layer grad_weight GEMMs autograd runs for nn.Linear in
+ * ImplicitNetwork / RenderingNetwork (implicit_differentiable_renderer.py:102,211-221).  K a multiple of 128 takes the
+ * grouped kernel, any other K falls back to hm_gemm_f32 for that item.  items is a [host] array.                     */
+#define HM_GEMM_GROUP_MAX 16
+typedef struct hm_gemm_group_item {
+    const float *A, *B;
+    float *C;
+    int64_t M, N, K, lda, ldb, ldc;
+} hm_gemm_group_item;
+HM_API int hm_gemm_f32_group_tn(const hm_gemm_group_item *items, int n_items, void *stream);
+
 /* ---- data-parallel gradient exchange (device side) ---------------------------------------------------
  * The reference runner is single-GPU (training/idr_train.py:92-93,278-321): there is no interface to
  * replace, the exchange is the build's own addition in the place the north star names - between loss.backward()
