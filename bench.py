@@ -235,29 +235,32 @@ def mlp_roofline(net, log2_n=18, iters=10, warmup=4):
 
 
 def gemm_roofline(device, iters=20, warmup=3):
-    """Exact-fp32 GEMM of the grad path (csrc/hm_gemm.hip) on the shapes one training step runs ~105 times: forward
-    X W^T (+ Softplus epilogue), input gradient dY W, weight gradient [u; z-bar]^T [v-bar; a] at 3072 / 2048 rows.
-    `achieved` = flops of the whole shape list / its time."""
+    """Exact-fp32 GEMM of the grad path (csrc/hm_gemm.hip) on the shapes one training step runs: forward X W^T (+ Softplus
+    epilogue) and input gradient dY W at 3072 / 2048 rows (~64 launches per step), and the weight gradients
+    [u; z-bar]^T [v-bar; a] of the 8 hidden layers of one backward pass as ONE grouped launch (hm_gemm_f32_group_tn; 3 such
+    launches per step).  `achieved` = flops of the whole list / its time."""
     from hashmodnffbanks_idr_amd import ops
-    shapes = []
+    entries = []   # (label dict, callable, flops)
     for rows in (3072, 2048):
-        shapes += [(rows, 512, 512, False, True, True), (rows, 512, 512, False, False, False),
-                   (512, 512, 2 * rows, True, False, False)]
-    ops_list, flops = [], 0.0
-    for (M, N, K, ta, tb, sp) in shapes:
-        a = torch.randn((K, M) if ta else (M, K), device=device)
-        b = torch.randn((N, K) if tb else (K, N), device=device)
-        out = torch.empty(M, N, device=device)
-        bias = torch.zeros(N, device=device) if sp else None
-        if sp:
-            fn = (lambda a=a, b=b, bias=bias: ops.gemm_ep(a, b, bias, False, True, ops.EPI_SOFTPLUS, 100.0, 20.0))
-        else:
-            fn = (lambda a=a, b=b, ta=ta, tb=tb, out=out: ops.gemm(a, b, None, ta, tb, out=out))
-        ops_list.append(fn)
-        flops += 2.0 * M * N * K
-    per_shape = []
+        for (M, N, K, ta, tb, sp) in ((rows, 512, 512, False, True, True), (rows, 512, 512, False, False, False)):
+            a = torch.randn((K, M) if ta else (M, K), device=device)
+            b = torch.randn((N, K) if tb else (K, N), device=device)
+            out = torch.empty(M, N, device=device)
+            bias = torch.zeros(N, device=device) if sp else None
+            if sp:
+                fn = (lambda a=a, b=b, bias=bias: ops.gemm_ep(a, b, bias, False, True, ops.EPI_SOFTPLUS, 100.0, 20.0))
+            else:
+                fn = (lambda a=a, b=b, ta=ta, tb=tb, out=out: ops.gemm(a, b, None, ta, tb, out=out))
+            entries.append(({"M": M, "N": N, "K": K, "transA": ta, "transB": tb, "softplus_epilogue": sp}, fn,
+                            2.0 * M * N * K))
+        probs = [(torch.randn(2 * rows, 512, device=device), torch.randn(2 * rows, 512, device=device),
+                  torch.zeros(512, 512, device=device)) for _ in range(8)]
+        entries.append(({"grouped": 8, "M": 512, "N": 512, "K": 2 * rows, "transA": True, "transB": False,
+                         "softplus_epilogue": False}, (lambda probs=probs: ops.gemm_group_tn(probs)),
+                        8 * 2.0 * 512 * 512 * 2 * rows))
+    per_shape, flops = [], 0.0
     side = torch.cuda.Stream()
-    for fn, sh in zip(ops_list, shapes):
+    for label, fn, fl in entries:
         for _ in range(warmup):
             fn()
         torch.cuda.synchronize()
@@ -275,15 +278,15 @@ def gemm_roofline(device, iters=20, warmup=3):
         e0.record()
         torch.cuda.synchronize()
         us = s0.elapsed_time(e0) / iters * 1e3
-        per_shape.append({"M": sh[0], "N": sh[1], "K": sh[2], "transA": sh[3], "transB": sh[4],
-                          "softplus_epilogue": sh[5], "us": round(us, 2),
-                          "TFLOP/s": round(2.0 * sh[0] * sh[1] * sh[2] / us / 1e6, 1)})
+        per_shape.append(dict(label, us=round(us, 2), **{"TFLOP/s": round(fl / us / 1e6, 1)}))
+        flops += fl
         del g
     total_us = sum(p["us"] for p in per_shape)
     tf = flops / total_us / 1e6
     return {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
             "frac": round(tf / MFMA_F32_PEAK_TF, 4), "traffic": None,
-            "kernel": "gemm_f32_pipe2_kernel (20 launches per shape replayed from a HIP graph, launch gaps included)",
+            "kernel": "gemm_f32_pipe2_kernel / gemm_f32_pipe2_group_kernel (20 launches per entry replayed from a HIP "
+                      "graph, launch gaps included)",
             "shapes": per_shape}
 
 

@@ -21,6 +21,7 @@
 #include "hm_common.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -239,6 +240,253 @@ __global__ __launch_bounds__(kNT) void nffb_fwd_kernel(HmLevels lv, NffbArgs a, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Big launches (the tracer's coarse scans: 200 - 400 k points): the SAME embedder tiled on the matrix cores.
+// In the lanes-per-point kernel above every POINT re-reads every weight matrix through the L1 (12.5 - 21 KB per
+// product, ~10 products: 41 GB of L1 traffic for the 410 k coarse points of config 3 -> 2.9 ms, bound by the L1, at
+// 4 % of the VALU peak).  Here a WAVE owns 16 points for the whole embedder and every product is
+//     Y[rows, 16 points] = Wm[rows, k] * V[k, 16 points]      on v_mfma_f32_16x16x4_f32 (exact fp32 fma chains),
+// so a weight matrix is read once per 16 points: A fragments are 16-byte loads of Wm[16t + (lane & 15)][16kb + 4(lane >> 4)
+// .. + 3] straight from the L1 (rows / k beyond W read as zero), B fragments are ds_read_b128 of the wave's activation
+// image V[k/4][point][4].  The accumulator of lane (point j, quarter q) holds rows 16t + 4q .. + 3 of tile t - exactly
+// one 16-byte k-group of the next product's V image (the identity the 16-point SDF body uses), so Sine, the positional
+// encoding, StyleAttention's per-row normalisation (two lane exchanges over the point's four lanes) and the feature
+// accumulation all run on the accumulator layout.  Waves share nothing: no workgroup barrier anywhere.
+typedef float nf_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kMfmaWaves = 4;      // waves per workgroup (16 points each)
+
+template <int W, int NT>
+__device__ __forceinline__ void nffb_matvec_mfma(const float *__restrict__ Wm, const float *src, nf_f32x4 (&acc)[NT],
+                                                 int j, int q) {
+    constexpr int KB = NT;                        // 16-wide k blocks of the padded K = 16 NT
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = nf_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        const int k0 = 16 * kb + 4 * q;
+        const float4 b = *reinterpret_cast<const float4 *>(src + ((4 * kb + q) * 16 + j) * 4);
+        float4 w[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int row = 16 * t + j;
+            const bool ok = row < W && k0 < W;    // (W % 4 == 0: a k-group is wholly inside or wholly outside)
+            const float4 v = *reinterpret_cast<const float4 *>(Wm + (ok ? row * W + k0 : 0));
+            w[t] = ok ? v : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t].x, b.x, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t].y, b.y, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t].z, b.z, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t].w, b.w, acc[t], 0, 0, 0);
+    }
+}
+
+template <int FRAC, int LV, bool STYLE>
+__global__ __launch_bounds__(64 * kMfmaWaves) void nffb_fwd_mfma_kernel(HmLevels lv, NffbArgs a, const float *__restrict__ x,
+                                                                        int64_t n, const float *__restrict__ table,
+                                                                        const float *__restrict__ Bf,
+                                                                        float *__restrict__ out, int64_t out_stride,
+                                                                        const int32_t *__restrict__ n_dev, int64_t run_min,
+                                                                        int64_t run_max) {
+    constexpr int W = 8 + 8 * LV;
+    constexpr int NT = (W + 15) / 16, WP = 16 * NT;     // 16-row tiles / padded width (64 at W = 56, 80 at W = 72)
+    constexpr int NG = 4 * (LV - 2);                    // grid values that are ever consumed: chunks 0 .. LV-3
+    constexpr int kImg = WP * 16;                       // floats of one activation image [WP/4][16][4]
+    __shared__ __align__(16) float lds[kMfmaWaves * (2 * kImg + 16 * NG)];
+    if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));
+    if (n < run_min || n > run_max) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+    float *XV = lds + wave * (2 * kImg + 16 * NG);      // trunk state
+    float *EV = XV + kImg;                              // positional encoding / style / sum image
+    float *G = EV + kImg;                               // [16][NG] consumed grid values of the wave's points
+    // the padded k-groups (rows W .. WP-1) are multiplied by zero weights: they must hold finite numbers
+    for (int i = lane; i < 2 * kImg; i += 64) XV[i] = 0.0f;
+    __builtin_amdgcn_wave_barrier();
+    const int64_t n_tiles = (n + 15) / 16;
+    for (int64_t tile = (int64_t)blockIdx.x * kMfmaWaves + wave; tile < n_tiles; tile += (int64_t)gridDim.x * kMfmaWaves) {
+        const int64_t i = tile * 16 + j;
+        const bool live = i < n;
+        const float p0 = live ? x[i * 3] : 0.0f, p1 = live ? x[i * 3 + 1] : 0.0f, p2 = live ? x[i * 3 + 2] : 0.0f;
+        const float xn[3] = {__fdiv_rn(p0, a.bound), __fdiv_rn(p1, a.bound), __fdiv_rn(p2, a.bound)};
+        const float two_b = __fmul_rn(2.0f, a.bound);
+        const float u0 = __fdiv_rn(__fadd_rn(p0, a.bound), two_b), u1 = __fdiv_rn(__fadd_rn(p1, a.bound), two_b),
+                    u2 = __fdiv_rn(__fadd_rn(p2, a.bound), two_b);
+        // ---- consumed part of the grid row [sin(L) | cos(L) | level features]: the point's four lanes share it ----
+        {
+            const float two_pi = 6.283185307179586f;
+            const float s0 = __fmul_rn(two_pi, u0), s1 = __fmul_rn(two_pi, u1), s2 = __fmul_rn(two_pi, u2);
+            for (int c = q; c < NG; c += 4) {
+                float v;
+                if (c < 2 * LV) {
+                    const int ch = c < LV ? c : c - LV;
+                    float ang = __fmul_rn(s0, Bf[ch]);
+                    ang = __fmaf_rn(s1, Bf[LV + ch], ang);
+                    ang = __fmaf_rn(s2, Bf[2 * LV + ch], ang);
+                    float sn, cs;
+                    sincosf(ang, &sn, &cs);
+                    v = c < LV ? sn : cs;
+                } else {
+                    const int l = (c - 2 * LV) >> 1, f = (c - 2 * LV) & 1;
+                    float acc = 0.0f;
+                    const float2 *tl = reinterpret_cast<const float2 *>(table) + lv.row_off[l];
+#pragma unroll
+                    for (int cc = 0; cc < 8; ++cc) {
+                        uint32_t ux, uy, uz;
+                        float wx, wy, wz;
+                        nffb_corner<FRAC>(u0, lv.res[l], cc & 1, ux, wx);
+                        nffb_corner<FRAC>(u1, lv.res[l], (cc >> 1) & 1, uy, wy);
+                        nffb_corner<FRAC>(u2, lv.res[l], (cc >> 2) & 1, uz, wz);
+                        const float w = __fmul_rn(__fmul_rn(wx, wy), wz);
+                        if (w != 0.0f) {
+                            const float2 r = tl[hm_mod_rows(hm_hash3(ux, uy, uz), lv.rows[l], lv.magic[l])];
+                            acc = __fadd_rn(acc, __fmul_rn(f ? r.y : r.x, w));
+                        }
+                    }
+                    v = acc;
+                }
+                G[j * NG + c] = v;
+            }
+        }
+        // ---- trunk layer 0: 3 -> W, sin(w0 .): the lane's rows 4g .. 4g+3 for the groups g = q, q+4, ... ---------------
+        for (int g = q; g < WP / 4; g += 4) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = 4 * g + e;
+                float y = 0.0f;
+                if (row < W) {
+                    const float *wr = a.trunk_w[0] + row * 3;
+                    float acc = __fmul_rn(wr[0], xn[0]);
+                    acc = __fmaf_rn(wr[1], xn[1], acc);
+                    acc = __fmaf_rn(wr[2], xn[2], acc);
+                    y = sinf(__fmul_rn(__fadd_rn(acc, a.trunk_b[0][row]), a.w0));
+                }
+                v[e] = y;
+            }
+            *reinterpret_cast<float4 *>(XV + (g * 16 + j) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        nf_f32x4 feat[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) feat[t] = nf_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+        for (int layer = 1; layer < LV - 1; ++layer) {
+            nf_f32x4 acc[NT];
+            // trunk: xv <- sin(w0 (W_l xv + b_l)), in place (every read of the old image precedes the writes)
+            nffb_matvec_mfma<W, NT>(a.trunk_w[layer], XV, acc, j, q);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = 16 * t + 4 * q + e;
+                    v[e] = row < W ? sinf(__fmul_rn(__fadd_rn(acc[t][e], a.trunk_b[layer][row]), a.w0)) : 0.0f;
+                }
+                *reinterpret_cast<float4 *>(XV + ((4 * t + q) * 16 + j) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            // positional encoding of chunk layer-1 into EV: group g holds entries 4g .. 4g+3 = f(c[0..3] * 2^m),
+            // f = identity (g < 2), sin (g even) or cos (g odd), m = (g - 2) / 2     (frequency_enc.py:6-51)
+            for (int g = q; g < WP / 4; g += 4) {
+                float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (4 * g < W) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float c = G[j * NG + 4 * (layer - 1) + e];
+                        float r = c;
+                        if (g >= 2) {
+                            const float arg = __fmul_rn(c, (float)(1 << ((g - 2) >> 1)));
+                            r = (g & 1) ? cosf(arg) : sinf(arg);
+                        }
+                        v[e] = r;
+                    }
+                }
+                *reinterpret_cast<float4 *>(EV + (g * 16 + j) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (STYLE) {
+                // StyleAttention: linear_transform(e) (its softmax over a size-1 dim is 1), then the per-row InstanceNorm
+                // over the W features (biased variance), styleMod.py:30-43; the point's rows sit in its four lanes
+                nffb_matvec_mfma<W, NT>(a.style_w, EV, acc, j, q);
+                float sum = 0.0f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int row = 16 * t + 4 * q + e;
+                        const float y = row < W ? __fadd_rn(acc[t][e], a.style_b[row]) : 0.0f;
+                        acc[t][e] = y;
+                        sum += y;
+                    }
+                sum += __shfl_xor(sum, 16);
+                sum += __shfl_xor(sum, 32);
+                const float mean = sum / (float)W;
+                float var = 0.0f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int row = 16 * t + 4 * q + e;
+                        const float d = row < W ? acc[t][e] - mean : 0.0f;
+                        var += d * d;
+                    }
+                var += __shfl_xor(var, 16);
+                var += __shfl_xor(var, 32);
+                const float den = sqrtf(var / (float)W + a.style_eps);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float4 xv = *reinterpret_cast<const float4 *>(XV + ((4 * t + q) * 16 + j) * 4);
+                    const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int row = 16 * t + 4 * q + e;
+                        v[e] = row < W ? __fadd_rn((acc[t][e] - mean) / den, xe[e]) : 0.0f;
+                    }
+                    *reinterpret_cast<float4 *>(EV + ((4 * t + q) * 16 + j) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    float4 *ep = reinterpret_cast<float4 *>(EV + ((4 * t + q) * 16 + j) * 4);
+                    const float4 ev = *ep, xv = *reinterpret_cast<const float4 *>(XV + ((4 * t + q) * 16 + j) * 4);
+                    *ep = make_float4(__fadd_rn(ev.x, xv.x), __fadd_rn(ev.y, xv.y), __fadd_rn(ev.z, xv.z), __fadd_rn(ev.w, xv.w));
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // shared output layer on e = posenc (+ style) + trunk; features accumulate in the accumulator layout
+            nffb_matvec_mfma<W, NT>(a.out_w, EV, acc, j, q);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = 16 * t + 4 * q + e;
+                    if (row < W) feat[t][e] = __fadd_rn(feat[t][e], __fadd_rn(acc[t][e], a.out_b[row]));
+                }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (live) {
+            float *o = out + i * out_stride;
+            if (q == 0) {
+                o[0] = u0; o[1] = u1; o[2] = u2;
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = 16 * t + 4 * q + e;
+                    if (row < W) o[3 + row] = __fdiv_rn(feat[t][e], (float)LV);
+                }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 template <int FRAC, int LV, bool STYLE>
@@ -255,9 +503,17 @@ int launch_nffb1(hipStream_t st, const HmLevels &lv, const NffbArgs &a, const fl
                            Bf, out, out_stride, n_dev, (int64_t)0, (int64_t)kSmallCount);
     }
     if (big) {
-        const int64_t blocks = (n + kNT / 8 - 1) / (kNT / 8);
-        hipLaunchKernelGGL((nffb_fwd_kernel<FRAC, LV, STYLE, 8>), dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(kNT),
-                           0, st, lv, a, x, n, table, Bf, out, out_stride, n_dev, (int64_t)kSmallCount + 1, kBig);
+        static const int mfma_cfg = [] { const char *e = getenv("HM_NFFB_MFMA"); return e ? atoi(e) : 1; }();
+        if (mfma_cfg) {     // matrix-core tiles, a wave per 16 points
+            const int64_t blocks = (n + 16 * kMfmaWaves - 1) / (16 * kMfmaWaves);
+            hipLaunchKernelGGL((nffb_fwd_mfma_kernel<FRAC, LV, STYLE>), dim3((unsigned)(blocks < 2048 ? blocks : 2048)),
+                               dim3(64 * kMfmaWaves), 0, st, lv, a, x, n, table, Bf, out, out_stride, n_dev,
+                               (int64_t)kSmallCount + 1, kBig);
+        } else {            // (HM_NFFB_MFMA=0: the 8-lanes-per-point VALU kernel, for A/B measurements)
+            const int64_t blocks = (n + kNT / 8 - 1) / (kNT / 8);
+            hipLaunchKernelGGL((nffb_fwd_kernel<FRAC, LV, STYLE, 8>), dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(kNT),
+                               0, st, lv, a, x, n, table, Bf, out, out_stride, n_dev, (int64_t)kSmallCount + 1, kBig);
+        }
     }
     return HM_OK;
 }

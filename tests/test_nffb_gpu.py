@@ -70,12 +70,17 @@ def test_fused_embedder_forward(golden, tag, et, L):
     np.testing.assert_allclose(yf.cpu().numpy(), ya.cpu().numpy(), rtol=1e-4, atol=2e-5)
     with torch.no_grad():
         assert emb(xr[:1]).shape == (1, 3 + 8 + 8 * L) and emb(xr[:0]).shape[0] == 0
-        # big launches (> 8192 points: 8 lanes per point) and small ones (32 lanes per point) give the same bits: every
-        # output row is one lane's k-ordered fma chain either way
+        # big launches (> 8192 points) run the matrix-core kernel (a wave per 16 points, v_mfma_f32_16x16x4_f32), small
+        # ones the 32-lanes-per-point VALU kernel: the same fp32 products in another summation order, and the SIREN
+        # trunk's sin(w0 .) amplifies last-bit differences - compared at the tolerance of the fixture comparison above
         xb = (torch.rand(20000 + 11, 3, device="cuda") * 2.2 - 1.1)
         yb = emb(xb)
         ys = torch.cat([emb(xb[i:i + 4000]) for i in range(0, xb.shape[0], 4000)], 0)
-        assert torch.equal(yb, ys)
+        d = (yb - ys).abs().max().item()
+        print(f"    matrix-core kernel vs lanes-per-point kernel on {xb.shape[0]} points: max |d| {d:.3e}")
+        np.testing.assert_allclose(yb.cpu().numpy(), ys.cpu().numpy(), rtol=1e-4, atol=2e-5)
+        from helpers import pin
+        pin(f"nffb:{tag}_L{L}:mfma_vs_valu_abs", d, floor=5e-6)
 
 
 @pytest.mark.parametrize("tag,et", [("ffb", "FFB"), ("stylemod", "StyleModNFFB")])
