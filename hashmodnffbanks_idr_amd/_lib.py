@@ -35,6 +35,8 @@ SIGNATURES = {
     "hm_encode_bwd_table_ws": (_int, [_p, _p, _i64, _p, _i64, _p, _int, _p, _i64, _p]),
     "hm_encode_rows": (_int, [_p, _p, _i64, _int, _p, _p, _p]),
     "hm_encode_bwd_table_sorted": (_int, [_p, _p, _p, _i64, _int, _p, _i64, _p, _p, _p]),
+    "hm_sort_workspace_bytes": (_i64, [_i64]),
+    "hm_sort_pairs_i32": (_int, [_p, _i64, _int, _p, _p, _p, _i64, _p]),
     "hm_encode_bwd_input": (_int, [_p, _p, _i64, _p, _p, _i64, _p, _p, _p]),
     "hm_encode_jvp": (_int, [_p, _p, _i64, _p, _p, _p, _i64, _p]),
     "hm_encode_bwd_table_jvp": (_int, [_p, _p, _i64, _p, _p, _i64, _p, _p]),

@@ -13,7 +13,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 ROOT = os.path.dirname(PKG)
 LIB = os.path.join(PKG, "libhashmod.so")
-SOURCES = ["hm_api.hip", "hm_encode.hip", "hm_sdf.hip", "hm_gemm.hip", "hm_trace.hip", "hm_elem.hip", "hm_pack.hip", "hm_optim.hip", "hm_loss.hip", "hm_nffb.hip", "hm_sdf_bf16.hip", "hm_encode_dx.hip", "hm_exchange.hip", "hm_sdf_split.hip"]
+SOURCES = ["hm_api.hip", "hm_encode.hip", "hm_sdf.hip", "hm_gemm.hip", "hm_trace.hip", "hm_elem.hip", "hm_pack.hip", "hm_optim.hip", "hm_loss.hip", "hm_nffb.hip", "hm_sdf_bf16.hip", "hm_encode_dx.hip", "hm_exchange.hip", "hm_sdf_split.hip", "hm_sort.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
          "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(kNT) void nffb_fwd_kernel(HmLevels lv, NffbArgs a, 
 // encoding, StyleAttention's per-row normalisation (two lane exchanges over the point's four lanes) and the feature
 // accumulation all run on the accumulator layout.  Waves share nothing: no workgroup barrier anywhere.
 typedef float nf_f32x4 __attribute__((ext_vector_type(4)));
-constexpr int kMfmaWaves = 4;      // waves per workgroup (16 points each)
+constexpr int kMfmaWaves = 4;      // waves per workgroup (16 points each) of the big-batch launch; 1 for the tracer's rounds
 
 template <int W, int NT>
 __device__ __forceinline__ void nffb_matvec_mfma(const float *__restrict__ Wm, const float *src, nf_f32x4 (&acc)[NT],
@@ -284,8 +284,8 @@ __device__ __forceinline__ void nffb_matvec_mfma(const float *__restrict__ Wm, c
     }
 }
 
-template <int FRAC, int LV, bool STYLE>
-__global__ __launch_bounds__(64 * kMfmaWaves) void nffb_fwd_mfma_kernel(HmLevels lv, NffbArgs a, const float *__restrict__ x,
+template <int FRAC, int LV, bool STYLE, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void nffb_fwd_mfma_kernel(HmLevels lv, NffbArgs a, const float *__restrict__ x,
                                                                         int64_t n, const float *__restrict__ table,
                                                                         const float *__restrict__ Bf,
                                                                         float *__restrict__ out, int64_t out_stride,
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(64 * kMfmaWaves) void nffb_fwd_mfma_kernel(HmLevels
     constexpr int NT = (W + 15) / 16, WP = 16 * NT;     // 16-row tiles / padded width (64 at W = 56, 80 at W = 72)
     constexpr int NG = 4 * (LV - 2);                    // grid values that are ever consumed: chunks 0 .. LV-3
     constexpr int kImg = WP * 16;                       // floats of one activation image [WP/4][16][4]
-    __shared__ __align__(16) float lds[kMfmaWaves * (2 * kImg + 16 * NG)];
+    __shared__ __align__(16) float lds[WAVES * (2 * kImg + 16 * NG)];
     if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));
     if (n < run_min || n > run_max) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(64 * kMfmaWaves) void nffb_fwd_mfma_kernel(HmLevels
     for (int i = lane; i < 2 * kImg; i += 64) XV[i] = 0.0f;
     __builtin_amdgcn_wave_barrier();
     const int64_t n_tiles = (n + 15) / 16;
-    for (int64_t tile = (int64_t)blockIdx.x * kMfmaWaves + wave; tile < n_tiles; tile += (int64_t)gridDim.x * kMfmaWaves) {
+    for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < n_tiles; tile += (int64_t)gridDim.x * WAVES) {
         const int64_t i = tile * 16 + j;
         const bool live = i < n;
         const float p0 = live ? x[i * 3] : 0.0f, p1 = live ? x[i * 3 + 1] : 0.0f, p2 = live ? x[i * 3 + 2] : 0.0f;
@@ -496,17 +496,23 @@ int launch_nffb1(hipStream_t st, const HmLevels &lv, const NffbArgs &a, const fl
     // once unless the live count falls in its range (like the fused SDF kernels)
     const bool small = n <= kSmallCount, big = n_dev ? n > kSmallCount : !small;
     const int64_t kBig = (int64_t)1 << 62;
+    static const int mfma_cfg = [] { const char *e = getenv("HM_NFFB_MFMA"); return e ? atoi(e) : 1; }();
     if (small || n_dev) {
         const int64_t cap = n < kSmallCount ? n : kSmallCount;
-        const int64_t blocks = (cap + kNT / 32 - 1) / (kNT / 32);
-        hipLaunchKernelGGL((nffb_fwd_kernel<FRAC, LV, STYLE, 32>), dim3((unsigned)blocks), dim3(kNT), 0, st, lv, a, x, n, table,
-                           Bf, out, out_stride, n_dev, (int64_t)0, (int64_t)kSmallCount);
+        if (mfma_cfg == 2) {   // (experiment: the matrix-core kernel for the tracer's rounds too, one wave per workgroup)
+            const int64_t blocks = (cap + 15) / 16;
+            hipLaunchKernelGGL((nffb_fwd_mfma_kernel<FRAC, LV, STYLE, 1>), dim3((unsigned)blocks), dim3(64), 0, st, lv, a, x, n,
+                               table, Bf, out, out_stride, n_dev, (int64_t)0, (int64_t)kSmallCount);
+        } else {
+            const int64_t blocks = (cap + kNT / 32 - 1) / (kNT / 32);
+            hipLaunchKernelGGL((nffb_fwd_kernel<FRAC, LV, STYLE, 32>), dim3((unsigned)blocks), dim3(kNT), 0, st, lv, a, x, n,
+                               table, Bf, out, out_stride, n_dev, (int64_t)0, (int64_t)kSmallCount);
+        }
     }
     if (big) {
-        static const int mfma_cfg = [] { const char *e = getenv("HM_NFFB_MFMA"); return e ? atoi(e) : 1; }();
         if (mfma_cfg) {     // matrix-core tiles, a wave per 16 points
             const int64_t blocks = (n + 16 * kMfmaWaves - 1) / (16 * kMfmaWaves);
-            hipLaunchKernelGGL((nffb_fwd_mfma_kernel<FRAC, LV, STYLE>), dim3((unsigned)(blocks < 2048 ? blocks : 2048)),
+            hipLaunchKernelGGL((nffb_fwd_mfma_kernel<FRAC, LV, STYLE, kMfmaWaves>), dim3((unsigned)(blocks < 2048 ? blocks : 2048)),
                                dim3(64 * kMfmaWaves), 0, st, lv, a, x, n, table, Bf, out, out_stride, n_dev,
                                (int64_t)kSmallCount + 1, kBig);
         } else {            // (HM_NFFB_MFMA=0: the 8-lanes-per-point VALU kernel, for A/B measurements)

@@ -110,7 +110,7 @@ def encode_fwd(desc, x, table, B, frac_mode=0, hash_only=False):
 
 def encode_bwd_table(desc, x, d_feat, frac_mode=0, out=None, deterministic=False):
     """Scatter-add of the hash-feature gradient d_feat [N,L*F] into a [rows,F] table gradient.
-    deterministic: sort the contributions by destination row (torch.sort, stable) and sum each row's run in one thread
+    deterministic: sort the contributions by destination row (sort_pairs: the library's stable radix sort) and sum each row's run in one thread
     (hm_encode_rows + hm_encode_bwd_table_sorted) instead of fp32 atomics - bitwise reproducible."""
     x = _prep_x(x)
     require_gpu(x, d_feat)
@@ -125,7 +125,7 @@ def encode_bwd_table(desc, x, d_feat, frac_mode=0, out=None, deterministic=False
         keys = torch.empty(n * desc.L * corners, dtype=torch.int32, device=x.device)
         wts = torch.empty(n * desc.L * corners, dtype=torch.float32, device=x.device) if corners == 8 else None
         check(lib().hm_encode_rows(desc.handle, dptr(x), n, int(frac_mode), dptr(keys), dptr(wts), stream_ptr(x)))
-        skeys, perm = torch.sort(keys, stable=True)
+        skeys, perm = sort_pairs(keys, max(int(desc.total_rows - 1).bit_length(), 1))
         check(lib().hm_encode_bwd_table_sorted(desc.handle, dptr(skeys), dptr(perm), keys.numel(), corners, dptr(d_feat),
                                                d_feat.stride(0), dptr(wts), dptr(out), stream_ptr(x)))
         return out
@@ -140,6 +140,29 @@ def encode_bwd_table(desc, x, d_feat, frac_mode=0, out=None, deterministic=False
     check(lib().hm_encode_bwd_table(desc.handle, dptr(x), n, dptr(d_feat), d_feat.stride(0), dptr(out),
                                     int(frac_mode), stream_ptr(x)))
     return out
+
+
+_SORT_WS = {}
+
+
+def sort_pairs(keys, key_bits=31):
+    """(sorted keys, permutation as int64) of non-negative int32 keys < 2^key_bits: the library's stable LSD radix sort
+    (hm_sort_pairs_i32), the sort behind encode_bwd_table(deterministic=True)."""
+    require_gpu(keys)
+    if keys.dtype != torch.int32 or keys.dim() != 1 or not keys.is_contiguous():
+        raise ValueError("hashmod sort_pairs: contiguous 1-D int32 keys expected")
+    n = keys.numel()
+    out = torch.empty_like(keys)
+    perm = torch.empty(n, dtype=torch.int64, device=keys.device)
+    if n == 0:
+        return out, perm
+    need = check(lib().hm_sort_workspace_bytes(n))
+    ws = _SORT_WS.get(keys.device)
+    if ws is None or ws.numel() < need:
+        ws = _SORT_WS[keys.device] = torch.empty(need, dtype=torch.uint8, device=keys.device)
+    check(lib().hm_sort_pairs_i32(dptr(keys), n, int(key_bits), dptr(out), dptr(perm), dptr(ws), ws.numel(),
+                                  stream_ptr(keys)))
+    return out, perm
 
 
 class _HashFeatures(torch.autograd.Function):

@@ -122,7 +122,8 @@ HM_API int hm_encode_bwd_table_ws(const hm_grid_desc *desc, const float *x, int6
 /* Deterministic form of the same gradient (no atomics).  hm_encode_rows lists, for every (point, level[, corner]),
  * the destination row in the fused table (keys_out [n*L*C] int32, C = 1 in reference frac mode - only corner 0 carries
  * weight - and 8 in trilinear mode, where weights_out [n*L*C] receives the interpolation weights).  The caller sorts
- * the keys with ANY stable sort (perm = the sorting permutation, int64); hm_encode_bwd_table_sorted then sums each run
+ * the keys with ANY stable sort (perm = the sorting permutation, int64; hm_sort_pairs_i32 below is the library's own);
+ * hm_encode_bwd_table_sorted then sums each run
  * of equal keys in sorted order in one thread and adds it to d_table with a plain read-modify-write.  Bitwise
  * reproducible for a given contribution order (torch's embedding_dense_backward is deterministic on the CPU path the
  * reference oracle runs; the atomic kernel above is the fast default).                                                */
@@ -131,6 +132,15 @@ HM_API int hm_encode_rows(const hm_grid_desc *desc, const float *x, int64_t n, i
 HM_API int hm_encode_bwd_table_sorted(const hm_grid_desc *desc, const int32_t *keys_sorted, const int64_t *perm,
                                       int64_t n_keys, int corners, const float *d_feat, int64_t d_feat_stride,
                                       const float *weights, float *d_table, void *stream);
+
+/* Stable sort of non-negative int32 keys (< 2^key_bits) with the sorting permutation - the library's own LSD radix sort
+ * (8-bit digits, ceil(key_bits/8) passes of three kernel launches; csrc/hm_sort.hip) for the pair
+ * hm_encode_rows -> hm_encode_bwd_table_sorted: keys_sorted[i] = keys[perm[i]], equal keys keep their input order.
+ * keys and keys_sorted must not alias; workspace: hm_sort_workspace_bytes(n) bytes.  Sync-free, graph-capturable.   */
+HM_API int64_t hm_sort_workspace_bytes(int64_t n);
+HM_API int hm_sort_pairs_i32(const int32_t *keys, int64_t n, int key_bits, int32_t *keys_sorted, int64_t *perm,
+                             void *workspace, int64_t workspace_bytes, void *stream);
+
 
 /* ---- encoder input gradient (frac_mode = HM_FRAC_TRILINEAR only) ---------------------------------------------
  * In the reference d(hash features)/dx is identically zero (xf = x - x.float() == 0, hashGridEmbedding.py:86), so

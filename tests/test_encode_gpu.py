@@ -394,3 +394,22 @@ def test_embedding_row_input_gradient_matches_torch_autograd(cfg):
         err = (a - b_).abs().max().item()
         print(f"embedding row {cfg} {name}: max |d| {err:.3e} (scale {scale:.3e})")
         assert scale > 0 and err <= 2e-5 * scale, name
+
+
+@pytest.mark.parametrize("n,bits", [(1, 5), (255, 8), (4096, 12), (4097, 23), (100003, 23), (300000, 25), (70001, 31)])
+def test_own_radix_sort_equals_stable_sort(n, bits):
+    """hm_sort_pairs_i32 (csrc/hm_sort.hip) against torch's stable sort: same sorted keys AND the same permutation (equal
+    keys keep their input order) - ragged sizes, every pass count (1 .. 4), heavy duplication"""
+    from hashmodnffbanks_idr_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(n)
+    hi = min((1 << bits) - 1, 2 ** 31 - 1)
+    keys = torch.randint(0, hi + 1, (n,), generator=g, dtype=torch.int64)
+    keys[: n // 3] = keys[: n // 3] % 17                  # many equal keys
+    if n > 10:
+        keys[-5:] = hi                                    # the largest key of the range
+    keys = keys.to(torch.int32).cuda()
+    sk, perm = ops.sort_pairs(keys, bits)
+    rk, rp = torch.sort(keys, stable=True)
+    assert torch.equal(sk, rk)
+    assert torch.equal(perm, rp)
+    assert ops.sort_pairs(keys[:0], bits)[0].numel() == 0
