@@ -772,10 +772,11 @@ __global__ __launch_bounds__(kBwdThreads) void encode_bwd_table_zorder_kernel(Hm
 
 // ---------------------------------------------------------------------------------------------------------
 // Deterministic table gradient (no atomics): contributions are keyed by their destination row, sorted by the caller
-// (any stable sort; torch.sort in ops.encode_bwd_table), and every run of equal keys is summed by ONE thread in
+// (any stable sort; ops.encode_bwd_table uses the library's own radix sort, csrc/hm_sort.hip), and every run of equal keys is summed by ONE thread in
 // sorted order and added to the table with a plain read-modify-write (each row has exactly one owner).  Bitwise
 // reproducible for a given contribution order - what keeps data-parallel replicas identical when every rank builds
-// its dense gradient from the same all-gathered contributions (parallel.PointGradExchange).
+// its dense gradient from the same all-gathered contributions (round 2's point exchange; round 3's
+// parallel.StaticGradExchange exchanges (row, value) lists and needs no sort).
 template <int FRAC>
 __global__ __launch_bounds__(kThreads) void encode_rows_kernel(HmLevels lv, const float *__restrict__ x, int64_t n,
                                                                int32_t *__restrict__ keys,
