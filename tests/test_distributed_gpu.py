@@ -195,3 +195,81 @@ def test_static_exchange_single_process_equals_plain_step():
     tab = "implicit_network.embed_model.embedder_obj.table"
     assert float((p1[tab] - p0[tab]).abs().max()) <= 2.5 * STEPS * LR
     assert float((p1[tab] - p0[tab]).abs().mean()) <= 0.05 * LR
+
+
+def test_exchange_kernels_single_process():
+    """device side of parallel.StaticGradExchange, kernel by kernel (csrc/hm_exchange.hip, hm_encode_bwd_table_tracked):
+    the tracked scatter equals the plain scatter and lists every touched row exactly once; pack empties the dense
+    gradient, the claim bits and (after clear) the counter; two ranks' lists applied in rank order give the mean of the
+    two dense gradients bit for bit on repeated runs; the flat bucket copy is exact."""
+    import ctypes as C
+    import params as P
+    from hashmodnffbanks_idr_amd import _lib, ops
+    L, T, b, d = P.CONFIGS["C1"]
+    res, rows = P.level_table(L, T, b, d)
+    desc = ops.GridDesc(res, rows, 2)
+    total = desc.total_rows
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(11)
+    lists, denses = [], []
+    for rank in range(2):
+        n = 3000 + 17 * rank
+        x = (torch.rand((n, 3), generator=g) * 2.2 - 1.1).to(dev)
+        x[1000:1200] = x[:200].clone()                                  # duplicates: rows touched by several points
+        df = torch.randn((n, L * 2), generator=g).to(dev)
+        ref = ops.encode_bwd_table(desc, x, df, 0)
+        dense = torch.zeros((total, 2), device=dev)
+        bits = torch.zeros((total + 31) // 32, dtype=torch.int32, device=dev)
+        count = torch.zeros(1, dtype=torch.int32, device=dev)
+        cap = n * L
+        rows_buf = torch.full((cap,), -7, dtype=torch.int32, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        half = n // 2                                                   # two scatter calls share the tracking buffers
+        for lo, hi in ((0, half), (half, n)):
+            _lib.check(_lib.lib().hm_encode_bwd_table_tracked(
+                desc.handle, _lib.dptr(x[lo:hi].contiguous()), hi - lo, _lib.dptr(df[lo:hi].contiguous()), L * 2,
+                _lib.dptr(dense), 0, _lib.dptr(bits), _lib.dptr(count), _lib.dptr(rows_buf), cap, _lib.stream_ptr(x)))
+        cnt = int(count.item())
+        listed = rows_buf[:cnt].long()
+        touched = torch.nonzero(ref.abs().sum(1) > 0).flatten()
+        assert cnt <= cap and torch.unique(listed).numel() == cnt, "a row was listed twice"
+        assert set(touched.tolist()) <= set(listed.tolist())            # (a touched row whose contributions cancel is listed too)
+        assert (dense - ref).abs().max().item() <= 3e-5 * ref.abs().max().item()
+        payload = torch.empty((cap, 3), dtype=torch.int32, device=dev)
+        dense_before = dense.clone()
+        _lib.check(_lib.lib().hm_rows_pack(_lib.dptr(dense), 2, _lib.dptr(rows_buf), _lib.dptr(count), cap, _lib.dptr(bits),
+                                           _lib.dptr(payload), _lib.dptr(status), _lib.stream_ptr(x)))
+        assert int(torch.count_nonzero(dense)) == 0 and int(torch.count_nonzero(bits)) == 0 and int(status.item()) == 0
+        assert torch.equal(payload[:cnt, 0].long().sort().values, listed.sort().values)
+        assert bool((payload[cnt:, 0] == -1).all())
+        vals = payload[:cnt, 1:].view(torch.float32)
+        assert torch.equal(vals, dense_before[payload[:cnt, 0].long()])
+        lists.append(payload)
+        denses.append(dense_before)
+    cap = max(p.shape[0] for p in lists)
+    gathered = torch.full((2, cap, 3), -1, dtype=torch.int32, device=dev)
+    gathered[:, :, 1:] = 0
+    for r, p in enumerate(lists):
+        gathered[r, :p.shape[0]] = p
+    outs = []
+    for _ in range(2):
+        acc = torch.zeros((total, 2), device=dev)
+        _lib.check(_lib.lib().hm_rows_apply(_lib.dptr(acc), total, 2, _lib.dptr(gathered), cap, cap * 3, 2, 0.5,
+                                            _lib.stream_ptr(acc)))
+        outs.append(acc.clone())
+    assert torch.equal(outs[0], outs[1])                                 # no atomics: bit-identical repeats
+    assert torch.equal(outs[0], denses[0] * 0.5 + denses[1] * 0.5)       # rank order: 0 + a/2, then + b/2
+    cnt_dev = torch.tensor([5], dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().hm_rows_clear(_lib.dptr(outs[0]), total, 2, _lib.dptr(gathered), cap, cap * 3, 2,
+                                        _lib.dptr(cnt_dev), _lib.stream_ptr(acc)))
+    assert int(torch.count_nonzero(outs[0])) == 0 and int(cnt_dev.item()) == 0
+    # flat bucket
+    srcs = [torch.randn(s, device=dev) for s in (1, 7, 4096, 8193, 512 * 512 + 3)]
+    flat = torch.zeros(sum(t.numel() for t in srcs) + 1, device=dev)
+    items = (_lib.CopyItem * len(srcs))()
+    off = 1                                                               # (odd offset: the unaligned path)
+    for i, t in enumerate(srcs):
+        items[i] = _lib.CopyItem(t.data_ptr(), flat.data_ptr() + 4 * off, t.numel())
+        off += t.numel()
+    _lib.check(_lib.lib().hm_multi_copy_f32(C.cast(items, C.c_void_p), len(srcs), _lib.stream_ptr(flat)))
+    assert torch.equal(flat[1:], torch.cat(srcs))

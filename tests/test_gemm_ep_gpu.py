@@ -81,3 +81,32 @@ def test_weight_norm_fold_multi_matches_torch():
         assert gg.shape == g.grad.shape
         for a, b in ((w, rw.detach()), (gv, v.grad), (gg, g.grad)):
             assert (a - b).abs().max().item() <= 2e-6 * max(b.abs().max().item(), 1e-6)
+
+
+def test_grouped_weight_gradient_gemm_matches_torch():
+    """hm_gemm_f32_group_tn: C_p += A_p^T B_p for a whole list in one launch - the layer shapes of the SDF / rendering
+    networks (partial edge tiles: 445, 257, 67, 281 columns), strided operand views, a K that is not a multiple of 128
+    (falls back to hm_gemm_f32 for that item), more items than one launch holds, accumulation into non-zero C"""
+    from hashmodnffbanks_idr_amd import ops
+    rs = np.random.RandomState(5)
+    T = lambda *s: torch.from_numpy(rs.standard_normal(s).astype(np.float32)).cuda()   # noqa: E731
+    shapes = [(6144, 512, 512), (6144, 445, 512), (6144, 512, 67), (3072, 257, 512), (4096, 512, 512), (2048, 512, 281),
+              (2048, 3, 512), (1000, 64, 96), (128, 65, 33)] + [(1024, 130, 70)] * 12          # 21 items > one launch
+    probs, refs = [], []
+    for (K, M, N) in shapes:
+        a_full, b_full = T(K, M + 5), T(K, N + 3)
+        a, b = a_full[:, 2:2 + M], b_full[:, :N]                      # views with row strides M + 5 / N + 3
+        c = T(M, N)
+        refs.append((c.double() + a.double().t() @ b.double()).float())
+        probs.append((a, b, c))
+    ops.gemm_group_tn(probs)
+    torch.cuda.synchronize()
+    worst = 0.0
+    for (a, b, c), ref, (K, M, N) in zip(probs, refs, shapes):
+        err = (c - ref).abs().max().item() / (np.sqrt(K) + 1e-30)
+        worst = max(worst, err)
+        np.testing.assert_allclose(c.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=2e-5 * np.sqrt(K))
+    print(f"grouped weight-gradient GEMM: worst |d| / sqrt(K) {worst:.3e}")
+    ops.gemm_group_tn([])                                             # empty list is a no-op
+    with pytest.raises(ValueError):
+        ops.gemm_group_tn([(T(8, 4), T(9, 4), T(4, 4))])              # inner dimensions differ
