@@ -61,11 +61,13 @@ SIGNATURES = {
     "hm_pack_mlp_layer_split": (_int, [_p, _i64, _int, _int, _int, C.c_float, C.c_float, _int, _p, _p]),
     "hm_sdf_fwd_split": (_int, [_p, _p, _p, _i64, _p, _p, _p, _i64, _int, _p, _i64, _p]),
     "hm_sdf_fwd_emb_split": (_int, [_p, _p, _i64, _int, _i64, _p, _i64, _p, _i64, _p]),
+    "hm_pack_mlp_layers": (_int, [_p, _int, _p]),
     "hm_pack_mlp_layer": (_int, [_p, _i64, _p, _int, _int, _int, _p, _p, _p, _p]),
     "hm_softplus": (_int, [_int, _p, _p, _p, _p, _p, _i64, C.c_float, C.c_float, _p]),
     "hm_sdf_head": (_int, [_int, _p, _i64, _i64, C.c_float, _p, _p, _p, _p, _p, _p]),
     "hm_colsum": (_int, [_p, _i64, _i64, _i64, _p, _p]),
     "hm_colsum_acc": (_int, [_p, _i64, _i64, _i64, _p, _p]),
+    "hm_colsum_acc_multi": (_int, [_p, _int, _p]),
     "hm_copy2d_f32": (_int, [_p, _i64, _p, _i64, _i64, _i64, _p]),
     "hm_idr_loss": (_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, C.c_float, C.c_float, C.c_float, _p, _p, _p, _p, _p]),
     "hm_adam_scratch_floats": (_i64, [_p, _int]),
@@ -103,6 +105,16 @@ class AdamTensor(C.Structure):
 class GemmGroupItem(C.Structure):
     _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("M", C.c_int64), ("N", C.c_int64),
                 ("K", C.c_int64), ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64)]
+
+
+class ColsumItem(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("M", C.c_int64), ("N", C.c_int64), ("ld", C.c_int64)]
+
+
+class PackItem(C.Structure):
+    _fields_ = [("W", C.c_void_p), ("bias", C.c_void_p), ("w_packed", C.c_void_p), ("w_packed_m16", C.c_void_p),
+                ("bias_padded", C.c_void_p), ("ldw", C.c_int64), ("out_dim", C.c_int32), ("seg_width0", C.c_int32),
+                ("seg_width1", C.c_int32), ("pad_", C.c_int32)]
 
 
 class CopyItem(C.Structure):

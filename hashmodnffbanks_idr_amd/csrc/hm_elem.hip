@@ -90,6 +90,28 @@ __global__ __launch_bounds__(kET) void colsum_kernel(const float *__restrict__ x
 }
 
 
+// the same for a list of matrices in ONE launch (the bias gradients of one backward pass): blockIdx.z = item
+struct ColsumTable {
+    hm_colsum_item it[HM_COLSUM_MAX_ITEMS];
+};
+__global__ __launch_bounds__(kET) void colsum_multi_kernel(ColsumTable t, int rows_per_block) {
+    const hm_colsum_item I = t.it[blockIdx.z];
+    const int64_t n = (int64_t)blockIdx.x * kET + threadIdx.x;
+    const int64_t m0 = (int64_t)blockIdx.y * rows_per_block;
+    if (n >= I.N || m0 >= I.M) return;
+    const int64_t m1 = min(I.M, m0 + rows_per_block);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
+    const int64_t ld = I.ld;
+    const float *p = I.x + m0 * ld + n;
+    int64_t m = m0;
+    for (; m + 8 <= m1; m += 8, p += 8 * ld) {
+        a0 += p[0]; a1 += p[ld]; a2 += p[2 * ld]; a3 += p[3 * ld];
+        a4 += p[4 * ld]; a5 += p[5 * ld]; a6 += p[6 * ld]; a7 += p[7 * ld];
+    }
+    for (; m < m1; ++m, p += ld) a0 += *p;
+    atomicAdd(I.out + n, ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7)));
+}
+
 // ---- soft clamp of the SDF column (implicit_differentiable_renderer.py:112, density_net.py:20-30) ----------------
 // forward: out = zL with column 0 replaced by sdf = tanh(s / (2 + rho(s))), rho under no_grad;
 //          c = d sdf / d s = (1 - sdf^2) / (2 + rho), denom = 2 + rho  (what the gradient sweeps reuse)
@@ -514,6 +536,34 @@ int hm_colsum(const float *x, int64_t M, int64_t N, int64_t ld, float *out, void
 
 int hm_colsum_acc(const float *x, int64_t M, int64_t N, int64_t ld, float *out, void *stream) {
     return colsum_impl(x, M, N, ld, out, false, stream);
+}
+
+int hm_colsum_acc_multi(const hm_colsum_item *items, int n_items, void *stream) {
+    HM_CHECK_ARG(n_items >= 0 && (n_items == 0 || items), "hm_colsum_acc_multi: bad argument");
+    for (int first = 0; first < n_items; first += HM_COLSUM_MAX_ITEMS) {
+        const int cnt = n_items - first < HM_COLSUM_MAX_ITEMS ? n_items - first : HM_COLSUM_MAX_ITEMS;
+        ColsumTable t;
+        int64_t max_n = 0, max_m = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const hm_colsum_item &I = items[first + i];
+            HM_CHECK_ARG(I.M >= 0 && I.N >= 0 && I.ld >= I.N && (I.M == 0 || I.N == 0 || (I.x && I.out)),
+                         "hm_colsum_acc_multi: bad item");
+            t.it[i] = I;
+            if (I.M > 0 && I.N > 0) {
+                max_n = I.N > max_n ? I.N : max_n;
+                max_m = I.M > max_m ? I.M : max_m;
+            }
+        }
+        for (int i = cnt; i < HM_COLSUM_MAX_ITEMS; ++i) t.it[i] = hm_colsum_item{nullptr, nullptr, 0, 0, 0};
+        if (max_n == 0) continue;
+        int rows = 32;
+        int64_t slabs = (max_m + rows - 1) / rows;
+        if (slabs > 65535) { rows = (int)((max_m + 65534) / 65535); slabs = (max_m + rows - 1) / rows; }
+        hipLaunchKernelGGL(colsum_multi_kernel, dim3((unsigned)((max_n + kET - 1) / kET), (unsigned)slabs, (unsigned)cnt),
+                           dim3(kET), 0, as_stream(stream), t, rows);
+    }
+    HM_CHECK_LAUNCH("hm_colsum_acc_multi");
+    return HM_OK;
 }
 
 }  // extern "C"

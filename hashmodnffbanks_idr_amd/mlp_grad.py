@@ -23,7 +23,7 @@ import math
 import torch
 
 from . import ops
-from .ops import (EPI_ADJOINT, EPI_RELU, EPI_RELUMASK, EPI_S1MUL, EPI_SOFTPLUS, _softplus_call, colsum_into, gemm,
+from .ops import (EPI_ADJOINT, EPI_RELU, EPI_RELUMASK, EPI_S1MUL, EPI_SOFTPLUS, _softplus_call, colsum_into_multi, gemm,
                   gemm_ep, gemm_group_tn)
 
 _SQRT2 = math.sqrt(2.0)
@@ -153,7 +153,7 @@ class _SdfMlp(torch.autograd.Function):
         # ONE grouped launch at the end (hm_gemm_f32_group_tn) instead of one split-K GEMM (+ its share of launches) per layer
         zb = ops.sdf_head_bwd(d_out, sdf, c, denom, cb)
         de = None
-        wgrad = []
+        wgrad, bgrad = [], []
         for l in range(L - 1, -1, -1):
             if need_w[l]:
                 if ustack[l] is not None:                        # zb IS ustack[l][N:] (written by layer l+1 below)
@@ -161,7 +161,7 @@ class _SdfMlp(torch.autograd.Function):
                 else:
                     wgrad.append((zb, a_list[l], dW[l]))
             if need_b[l]:
-                colsum_into(zb, db[l])
+                bgrad.append((zb, db[l]))                        # column sums: one launch for all layers, below
             if l > 0:
                 # a-bar_l = z-bar_l W_l; z-bar_{l-1} = a-bar_l[:, :dh] * s1(z_{l-1}) (+ the adjoint sweep's share)
                 dh = z_list[l - 1].shape[1]
@@ -176,6 +176,7 @@ class _SdfMlp(torch.autograd.Function):
                 ab = gemm(zb, Ws[l], None, False, False)
                 de = ab if de is None else de + ab
         gemm_group_tn(wgrad)
+        colsum_into_multi(bgrad)
         d_e = de if ctx.needs_input_grad[0] else None
         return (d_e, None, None, None, None, *dW, *db)
 
@@ -221,17 +222,18 @@ class _ReluMlp(torch.autograd.Function):
             torch._foreach_zero_(zero_list)
         zb = d_y.contiguous()
         dx = None
-        wgrad = []
+        wgrad, bgrad = [], []
         for l in range(L - 1, -1, -1):
             if need_w[l]:
                 wgrad.append((zb, acts[l], dW[l]))
             if need_b[l]:
-                colsum_into(zb, db[l])
+                bgrad.append((zb, db[l]))
             if l > 0:     # h-bar_l = z-bar_l W_l, masked by relu'(z_{l-1}) = (h_l > 0)
                 zb = gemm_ep(zb, Ws[l], None, False, False, EPI_RELUMASK, 0.0, 0.0, z=acts[l], want_c=False)[1]
             elif ctx.needs_input_grad[0]:
                 dx = gemm(zb, Ws[0], None, False, False)
         gemm_group_tn(wgrad)
+        colsum_into_multi(bgrad)
         return (dx, *dW, *db)
 
 

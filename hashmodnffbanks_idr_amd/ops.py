@@ -599,6 +599,8 @@ class PackedSdf:
 
     def update(self, weights, biases, beta):
         self.desc.beta = float(beta)
+        items = (_lib.PackItem * len(self.bufs))()
+        self.keep = []
         for l, (img8, img16, bpad) in enumerate(self.bufs):
             out_dim, w0, w1 = self.segs[l]
             W = weights[l].detach()
@@ -608,9 +610,9 @@ class PackedSdf:
             if b.dtype != torch.float32 or not b.is_contiguous():
                 b = b.float().contiguous()
             require_gpu(W, b)
-            self.keep = [W, b]
-            check(lib().hm_pack_mlp_layer(dptr(W), W.stride(0), dptr(b), out_dim, w0, w1, dptr(img8), dptr(img16),
-                                          dptr(bpad), stream_ptr(W)))
+            self.keep += [W, b]
+            items[l] = _lib.PackItem(W.data_ptr(), b.data_ptr(), img8.data_ptr(), img16.data_ptr(), bpad.data_ptr(),
+                                     W.stride(0), out_dim, w0, w1, 0)
             if self.has_bf16:
                 check(lib().hm_pack_mlp_layer_bf16(dptr(W), W.stride(0), out_dim, w0, w1, dptr(self.bf16[l]),
                                                    stream_ptr(W)))
@@ -618,6 +620,8 @@ class PackedSdf:
                 s0, s1 = self.split_scales[l]
                 check(lib().hm_pack_mlp_layer_split(dptr(W), W.stride(0), out_dim, w0, w1, s0, s1, self.desc.split_kind,
                                                     dptr(self.split_imgs[l]), stream_ptr(W)))
+        # all fp32 operand images (8-k, 16-k) and padded biases in ONE launch
+        check(lib().hm_pack_mlp_layers(C.cast(items, C.c_void_p), len(self.bufs), stream_ptr(self.bufs[0][0])))
 
 
 def sdf_fwd(desc, packed, x, table, B, frac_mode=0, sdf_only=False, max_workgroups=0, tile_points=0, n_dev=None):
@@ -914,6 +918,20 @@ def colsum_into(x, out):
     x = _rowmajor(x)
     check(lib().hm_colsum_acc(dptr(x), x.shape[0], x.shape[1], _ld(x), dptr(out), stream_ptr(x)))
     return out
+
+
+def colsum_into_multi(pairs):
+    """out += column sums of x for every (x, out) of `pairs` in ONE launch (hm_colsum_acc_multi)."""
+    if not pairs:
+        return
+    items = (_lib.ColsumItem * len(pairs))()
+    keep = []
+    for i, (x, out) in enumerate(pairs):
+        require_gpu(x, out)
+        x = _rowmajor(x)
+        keep.append(x)
+        items[i] = _lib.ColsumItem(x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], _ld(x))
+    check(lib().hm_colsum_acc_multi(C.cast(items, C.c_void_p), len(pairs), stream_ptr(pairs[0][0])))
 
 
 def _softplus_call(order, z, gy, gg, beta, thr):

@@ -232,6 +232,16 @@ typedef struct hm_mlp_desc {
 HM_API int hm_pack_mlp_layer(const float *W, int64_t ldw, const float *bias, int out_dim, int seg_width0,
                              int seg_width1, float *w_packed, float *w_packed_m16, float *bias_padded,
                              void *stream);
+/* the same for every layer of a network in ONE launch (the per-step re-pack); items is a [host] array of at most
+ * HM_MAX_LAYERS entries with the arguments of hm_pack_mlp_layer                                                  */
+typedef struct hm_pack_item {
+    const float *W;
+    const float *bias;
+    float *w_packed, *w_packed_m16, *bias_padded;
+    int64_t ldw;
+    int32_t out_dim, seg_width0, seg_width1, pad_;
+} hm_pack_item;
+HM_API int hm_pack_mlp_layers(const hm_pack_item *items, int n_items, void *stream);
 
 HM_API int hm_pack_mlp_layer_bf16(const float *W, int64_t ldw, int out_dim, int seg_width0, int seg_width1,
                                   void *w_packed_bf16, void *stream);
@@ -466,6 +476,15 @@ HM_API int hm_sdf_head(int backward, const float *in, int64_t n, int64_t cols, f
 HM_API int hm_colsum(const float *x, int64_t M, int64_t N, int64_t ld, float *out, void *stream);
 /* same, added into out (no zeroing: the caller zeroes all its gradient buffers with one launch)  */
 HM_API int hm_colsum_acc(const float *x, int64_t M, int64_t N, int64_t ld, float *out, void *stream);
+/* out_i[n] += sum_m x_i[m, n] for a list of matrices in ONE launch (all bias gradients of one backward pass; the caller
+ * zeroes the outputs).  items is a [host] array.                                                                 */
+#define HM_COLSUM_MAX_ITEMS 16
+typedef struct hm_colsum_item {
+    const float *x;
+    float *out;
+    int64_t M, N, ld;
+} hm_colsum_item;
+HM_API int hm_colsum_acc_multi(const hm_colsum_item *items, int n_items, void *stream);
 
 /* dst[r*ld_dst + c] = src[r*ld_src + c], r < rows, c < cols, as an ordinary kernel: the copies torch would issue as
  * hipMemcpyAsync (Tensor.copy_ / clone of contiguous tensors; the saved-activation stacking of the fused MLP-gradient
