@@ -165,16 +165,21 @@ def test_idr_training_steps(golden, merge, cfg, n_steps):
             print(f"    parameters after one Adam step: worst fraction of sampled entries off by a sign flip {worst:.3f}")
 
 
-def test_graphed_step_C2_matches_reference(golden):
+@pytest.mark.parametrize("coarse", [None, "f16x2"])
+def test_graphed_step_C2_matches_reference(golden, coarse):
     """ONE captured-graph iteration at the benchmarked configuration (C2, 2048 rays) against the reference's own
     first iteration on the same random draws.  lr = 0 keeps the parameters at their initial values through the two
     eager warm-up iterations and the capture, and the CPU generator is re-seeded before every step, so the first
-    REPLAYED iteration computes exactly what the reference's step 0 did."""
+    REPLAYED iteration computes exactly what the reference's step 0 did.
+    coarse = "f16x2": the same iteration with the tracer's coarse scans on the split-operand kernel (22-bit operands on
+    the 16-bit matrix cores) is held to the SAME comparison with the reference's recorded iteration - mask flips, loss
+    terms, gradient norms, per-ray outputs (bench.py's split_f16x2_leg)."""
     from hashmodnffbanks_idr_amd.model.loss import IDRLoss
     from hashmodnffbanks_idr_amd.training.graph_step import GraphedTrainStep
     from hashmodnffbanks_idr_amd.training.optim import ClipAdam
     g = golden("idr_step_C2")
     model = _model(g, "C2")
+    model.implicit_network.coarse_split = coarse
     model.train()
     inp = {k: torch.from_numpy(g[k]).cuda() for k in ("intrinsics", "uv", "pose", "object_mask")}
     gt = {"rgb": torch.from_numpy(g["rgb_gt"]).cuda()}
@@ -191,7 +196,8 @@ def test_graphed_step_C2_matches_reference(golden):
     assert np.array_equal(stepper.static["eik"].cpu().numpy(), g["s0:draw1"])
     st = model.ray_tracer.last_stats
     assert st["unfinished"] == 0 and st.get("nonfinite", 0) == 0
-    _check_first_step(g, out, lo, float(opt.last_grad_norm.item()), model, n_rays, "C2 captured graph")
+    _check_first_step(g, out, lo, float(opt.last_grad_norm.item()), model, n_rays,
+                      "C2 captured graph" + (f" {coarse} coarse scans" if coarse else ""))
 
 
 @pytest.mark.parametrize("tag", ["C3", "C5"])
