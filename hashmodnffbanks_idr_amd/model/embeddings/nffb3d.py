@@ -111,6 +111,8 @@ class FourierFilterBanks(nn.Module):
         x = input / self.bound
         u = (input + self.bound) / (2 * self.bound)
         grid = self.grid_enc(u)[..., x.shape[-1]:]
+        if self._batched_levels_ok(input):
+            return self._forward_batched_levels(x, u, grid)
         chunks = grid.view(-1, self.grid_levels, 2 * self.max_points_per_level).permute(1, 0, 2)
         # only chunks 0 .. L-3 are ever consumed (layers 1 .. L-2)
         enc = [self.ff_enc[i](chunks[i]) for i in range(self.n_nffb_layers - 2)]
@@ -125,4 +127,39 @@ class FourierFilterBanks(nn.Module):
                 e = e + x
                 f = ops.linear(e, self.out_layer.weight, self.out_layer.bias)
                 feats = f if feats is None else feats + f
+        return torch.cat([u, feats / self.grid_levels], dim=-1)
+
+    def _batched_levels_ok(self, input):
+        """the grad path's level-batched form needs the fused per-row ops (posenc, rownorm) - CUDA, fp32, grad enabled"""
+        if not (input.is_cuda and input.dtype == torch.float32 and torch.is_grad_enabled() and self.include_input):
+            return False
+        if self.modulationApplied and not (self.StyleAttentionBlock.fused_norm and
+                                           self.StyleAttentionBlock.feature_vector_size <= 128):
+            return False
+        return getattr(self, "batch_levels", True)
+
+    def _forward_batched_levels(self, x, u, grid):
+        """The same function with the per-level work batched over the levels (grad path).  The positional encodings and
+        StyleAttention act row by row with weights shared by all levels, and the shared `out_layer` is linear:
+            sum_l out_layer(e_l + x_l) = out_layer(sum_l e_l + sum_l x_l) + (n - 1) bias,
+        so the L-2 consumed chunks are stacked into ONE [N (L-2), 4] matrix for one posenc (+ one linear_transform and
+        one row normalisation), and ONE out_layer GEMM runs on the level sum.  Per evaluation that is 1 + 1 + 1 + 1
+        launches instead of (L-2) x 4, and as many GEMMs / elementwise passes less in every backward and double-backward
+        pass over the embedder - the filter-bank steps are launch-bound.  Equal to the level-by-level
+        form up to the order of fp32 additions (reference: nffb3d.py:160-194)."""
+        N = grid.shape[0]
+        nl = self.n_nffb_layers - 2                      # consumed chunks: 0 .. L-3
+        cw = 2 * self.max_points_per_level
+        C = grid.reshape(N, self.grid_levels, cw)[:, :nl].reshape(N * nl, cw)      # row = (point, level)
+        E = self.ff_enc[0](C)                            # every level's encoder has the same frequencies
+        if self.modulationApplied:
+            E = self.StyleAttentionBlock(u, E)           # (fused path: `content` only contributes its exact-zero term)
+        xs = None
+        for layer in range(self.n_nffb_layers - 1):
+            lin = getattr(self, 'ff_lin' + str(layer))
+            x = self.lin_activation(ops.linear(x, lin.weight, lin.bias))
+            if layer > 0:
+                xs = x if xs is None else xs + x
+        S = E.view(N, nl, E.shape[1]).sum(1) + xs        # sum over the levels of (e_l + x_l)
+        feats = ops.linear(S, self.out_layer.weight, self.out_layer.bias * float(nl))
         return torch.cat([u, feats / self.grid_levels], dim=-1)
