@@ -9,7 +9,7 @@ python - <<'PY'
 import json
 d=json.load(open('gpurun_out/r3q/bench_line.json'))
 print('headline', d['value'], d['ms_per_step'])
-for k in ('train_leg','lazy_sampler_leg','split_f16x2_leg','config4_leg','config3_leg','config5_leg','config5_leg_bf16x2'):
+for k in ('train_leg','lazy_sampler_leg','split_f16x2_leg','config4_leg','config3_leg','config5_leg','config5_leg_plain_bf16'):
     if k in d: print(k, d[k]['value'], d[k]['ms_per_step'])
 for k in d:
     if k.startswith('roofline'): print(k, d[k].get('achieved'), d[k].get('frac'), d[k].get('avg_launch_ms'))

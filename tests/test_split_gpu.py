@@ -175,9 +175,10 @@ def test_loss_curve_50_steps_split_vs_fp32_on_stylemod(golden, kind):
     print(f"{kind}:", [f"{v:.5f}" for v in b[[0, 1, 2, 5, 10, 25, 49]]])
     print(f"StyleModNFFB 50-step loss curves fp32 vs {kind}-coarse, 10-step windows rel diff {np.round(rel_w, 4).tolist()} "
           f"(fp32 vs fp32: {np.round(spread_w, 4).tolist()}); per-step max {rel.max():.3e} (fp32 vs fp32 {spread.max():.3e})")
-    # this network's training is chaotic (sin(30 .) trunk, lr 1e-4): two fp32 runs that differ only in the order of their
-    # fp32 atomics decorrelate after ~20 steps (window deviations between 0.3 % and 9.4 % were measured between fp32 pairs
-    # in windows 2 - 4 over five calibration runs), so a pathwise comparison means something only inside that horizon: the
-    # 2 % criterion is ASSERTED on the first two windows (steps 0 - 19), the other three are reported and bounded loosely
+    # this network's training is chaotic (sin(30 .) trunk, lr 1e-4): a perturbation grows until the trajectories
+    # decorrelate, and its size sets when - fp32 pairs (atomics-order noise) stay within 0.1 % for ~30 steps and were
+    # 0.3 - 9.4 % apart in windows 3 - 4 over six runs of round 3; bf16x2 (kernel error 5e-6) stays for ~20 steps, plain
+    # bf16 (1.2e-3) for ~10 (tests/test_bf16_gpu.py).  The 2 % criterion is therefore ASSERTED on the first two windows
+    # (steps 0 - 19), the other three are reported and bounded loosely
     assert rel_w[:2].max() <= 0.02 + spread_w[:2].max(), (rel_w, spread_w)
     assert rel_w.max() <= 0.30 and np.isfinite(b).all()
