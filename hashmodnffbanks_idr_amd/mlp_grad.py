@@ -37,7 +37,7 @@ class _SdfMlp(torch.autograd.Function):
     v-bar_l during backward; `ustack[l]` [2N, out_l] is filled the same way with u_l and z-bar_l."""
 
     @staticmethod
-    def forward(ctx, e, skip_layer, beta_sp, thr_sp, beta_rho, *params):
+    def forward(ctx, e, skip_layer, beta_sp, thr_sp, beta_rho, cache_out, *params):
         L = len(params) // 2
         Ws, bs = params[:L], params[L:]
         N, E = e.shape
@@ -88,104 +88,160 @@ class _SdfMlp(torch.autograd.Function):
         ctx.meta = (L, skip_layer, beta_sp, thr_sp, E)
         ctx.stack = stack      # internal buffers (their lower halves are the saved a_l views)
         ctx.save_for_backward(e, sdf, c, denom, *Ws, *a_list, *z_list, *v_list)
+        if cache_out is not None:     # lets a second node over a ROW RANGE of this batch skip its forward (_SdfMlpRows)
+            cache_out.update(meta=ctx.meta, out=out, g_e=g_e, sdf=sdf, c=c, denom=denom, a_list=a_list, z_list=z_list,
+                             v_list=v_list, Ws=Ws)
         return out, g_e
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, d_out, d_ge):
-        L, skip_layer, beta_sp, thr_sp, E = ctx.meta
-        sv = ctx.saved_tensors
-        e, sdf, c, denom = sv[0], sv[1], sv[2], sv[3]
-        Ws = sv[4:4 + L]
-        a_list = sv[4 + L:4 + 2 * L]
-        z_list = sv[4 + 2 * L:4 + 3 * L]
-        v_list = sv[4 + 3 * L:4 + 4 * L]
-        stack = ctx.stack
-        N = e.shape[0]
-        need_w = ctx.needs_input_grad[5:5 + L]
-        new = lambda r, c_: torch.empty((r, c_), dtype=torch.float32, device=e.device)  # noqa: E731
-        # every weight / bias gradient accumulates with atomics (split-K GEMMs, column sums): the buffers are zeroed
-        # here by ONE multi-tensor launch instead of one zeroing launch in front of each producer
-        need_b = ctx.needs_input_grad[5 + L:5 + 2 * L]
-        bshape = [z.shape[1] for z in z_list]
-        dW = [torch.empty_like(Ws[l]) if need_w[l] else None for l in range(L)]
-        db = [torch.empty(bshape[l], dtype=torch.float32, device=e.device) if need_b[l] else None for l in range(L)]
-        zero_list = [t for t in dW + db if t is not None]
-        if zero_list:
-            torch._foreach_zero_(zero_list)
-        zx = [None] * L       # extra z-bar from the adjoint of the gradient sweep
-        ustack = [None] * L   # [u_l; z-bar_l] of the layers whose weight gradient is one stacked GEMM
-        cb = None
+        L = ctx.meta[0]
+        grads = _sdf_mlp_backward(ctx.meta, ctx.saved_tensors, ctx.stack, ctx.needs_input_grad[0],
+                                  ctx.needs_input_grad[6:6 + L], ctx.needs_input_grad[6 + L:6 + 2 * L], d_out, d_ge)
+        return (grads[0], None, None, None, None, None, *grads[1:])
 
-        # ---- adjoint of the gradient sweep (walks the layers upwards) --------------------------------------
-        if d_ge is not None:
-            d_ge = d_ge.contiguous()
-            vb_h = d_ge                                          # v-bar of layer 0 (hidden part)
-            for l in range(L):
-                stacked = l < L - 1 and bool(need_w[l])
-                if l == skip_layer:
-                    vb = (torch.cat([vb_h, d_ge], 1, out=stack[l][:N]) if stacked else torch.cat([vb_h, d_ge], 1))
-                    vb = vb.div_(_SQRT2)
-                elif stacked and vb_h.data_ptr() != stack[l].data_ptr():
-                    vb = ops.dcopy_(stack[l][:N], vb_h)          # (layer 0, or after an unstacked layer)
-                else:
-                    vb = vb_h
-                if l < L - 1:
-                    # u-bar_l = v-bar_l W_l^T and, on its accumulators, the adjoint of u_l = v_{l+1}[:, :dh] * s1(z_l):
-                    #   v-bar_{l+1} = u-bar * s1,  extra z-bar_l = u-bar * v_{l+1} * s2,  u_l itself (for W-bar_l)
-                    if stacked:
-                        ustack[l] = new(2 * N, Ws[l].shape[0])
-                    nxt = l + 1
-                    dst = stack[nxt][:N] if (nxt < L - 1 and nxt != skip_layer and need_w[nxt]) else None
-                    vb_h, zx[l], _ = gemm_ep(vb, Ws[l], None, False, True, EPI_ADJOINT, beta_sp, thr_sp,
-                                             z=z_list[l], g=v_list[l + 1], out1=dst,
-                                             out3=ustack[l][:N] if stacked else None)
-                else:
-                    # last layer: u = c * onehot(0).  c-bar = u-bar[:, 0] = v-bar W[0]^T;  W-bar[0] = c^T v-bar
-                    # (both on the library's GEMM: torch.matmul would put a vendor GEMV and, for the row assignment,
-                    #  a MEMCPY node into the captured iteration)
-                    cb = gemm(vb, Ws[l][0:1], None, False, True)             # [N, 1]
-                    if need_w[l]:
-                        gemm(c.view(N, 1), vb, None, True, False, out=dW[l][0:1], accumulate=True)
 
-        # ---- backward of the forward sweep (walks the layers downwards) ------------------------------------
-        # the weight gradients are independent of one another and of the rest of the sweep: they are collected and run as
-        # ONE grouped launch at the end (hm_gemm_f32_group_tn) instead of one split-K GEMM (+ its share of launches) per layer
-        zb = ops.sdf_head_bwd(d_out, sdf, c, denom, cb)
-        de = None
-        wgrad, bgrad = [], []
-        for l in range(L - 1, -1, -1):
-            if need_w[l]:
-                if ustack[l] is not None:                        # zb IS ustack[l][N:] (written by layer l+1 below)
-                    wgrad.append((ustack[l], stack[l], dW[l]))                                  # [u; z-bar]^T [v-bar; a]
-                else:
-                    wgrad.append((zb, a_list[l], dW[l]))
-            if need_b[l]:
-                bgrad.append((zb, db[l]))                        # column sums: one launch for all layers, below
-            if l > 0:
-                # a-bar_l = z-bar_l W_l; z-bar_{l-1} = a-bar_l[:, :dh] * s1(z_{l-1}) (+ the adjoint sweep's share)
-                dh = z_list[l - 1].shape[1]
-                is_skip = l == skip_layer
-                dst = ustack[l - 1][N:] if ustack[l - 1] is not None else None
-                ab, zb = gemm_ep(zb, Ws[l], None, False, False, EPI_S1MUL, beta_sp, thr_sp,
-                                 scale=1.0 / _SQRT2 if is_skip else 1.0, z=z_list[l - 1], g=zx[l - 1], nz=dh,
-                                 want_c=is_skip, out1=dst)
-                if is_skip:
-                    de = ab[:, dh:] if de is None else de + ab[:, dh:]
+def _sdf_mlp_backward(meta, sv, stack, need_e, need_w, need_b, d_out, d_ge):
+    """Analytic reverse-over-reverse of the forward sweep and the gradient sweep (see the module docstring).
+    stack: the forward's [2N, in_l] buffers (weight gradients as ONE stacked product per layer), or None (a node that
+    reuses another node's saved activations, _SdfMlpRows: u^T v-bar and z-bar^T a are two entries of the grouped launch)."""
+    L, skip_layer, beta_sp, thr_sp, E = meta
+    e, sdf, c, denom = sv[0], sv[1], sv[2], sv[3]
+    Ws = sv[4:4 + L]
+    a_list = sv[4 + L:4 + 2 * L]
+    z_list = sv[4 + 2 * L:4 + 3 * L]
+    v_list = sv[4 + 3 * L:4 + 4 * L]
+    use_stack = stack is not None
+    N = e.shape[0]
+    new = lambda r, c_: torch.empty((r, c_), dtype=torch.float32, device=e.device)  # noqa: E731
+    # every weight / bias gradient accumulates with atomics (grouped GEMM, column sums): the buffers are zeroed
+    # here by ONE multi-tensor launch instead of one zeroing launch in front of each producer
+    bshape = [z.shape[1] for z in z_list]
+    dW = [torch.empty_like(Ws[l]) if need_w[l] else None for l in range(L)]
+    db = [torch.empty(bshape[l], dtype=torch.float32, device=e.device) if need_b[l] else None for l in range(L)]
+    zero_list = [t for t in dW + db if t is not None]
+    if zero_list:
+        torch._foreach_zero_(zero_list)
+    zx = [None] * L       # extra z-bar from the adjoint of the gradient sweep
+    ustack = [None] * L   # [u_l; z-bar_l] of the layers whose weight gradient is one stacked GEMM
+    cb = None
+    wgrad, bgrad = [], []
+
+    # ---- adjoint of the gradient sweep (walks the layers upwards) --------------------------------------
+    if d_ge is not None:
+        d_ge = d_ge.contiguous()
+        vb_h = d_ge                                          # v-bar of layer 0 (hidden part)
+        for l in range(L):
+            stacked = use_stack and l < L - 1 and bool(need_w[l])
+            if l == skip_layer:
+                vb = (torch.cat([vb_h, d_ge], 1, out=stack[l][:N]) if stacked else torch.cat([vb_h, d_ge], 1))
+                vb = vb.div_(_SQRT2)
+            elif stacked and vb_h.data_ptr() != stack[l].data_ptr():
+                vb = ops.dcopy_(stack[l][:N], vb_h)          # (layer 0, or after an unstacked layer)
             else:
-                ab = gemm(zb, Ws[l], None, False, False)
-                de = ab if de is None else de + ab
-        gemm_group_tn(wgrad)
-        colsum_into_multi(bgrad)
-        d_e = de if ctx.needs_input_grad[0] else None
-        return (d_e, None, None, None, None, *dW, *db)
+                vb = vb_h
+            if l < L - 1:
+                # u-bar_l = v-bar_l W_l^T and, on its accumulators, the adjoint of u_l = v_{l+1}[:, :dh] * s1(z_l):
+                #   v-bar_{l+1} = u-bar * s1,  extra z-bar_l = u-bar * v_{l+1} * s2,  u_l itself (for W-bar_l)
+                if stacked:
+                    ustack[l] = new(2 * N, Ws[l].shape[0])
+                nxt = l + 1
+                dst = stack[nxt][:N] if (use_stack and nxt < L - 1 and nxt != skip_layer and need_w[nxt]) else None
+                loose = (not stacked) and bool(need_w[l])    # u_l as a tensor of its own: u^T v-bar joins the grouped launch
+                vb_h, zx[l], u_l = gemm_ep(vb, Ws[l], None, False, True, EPI_ADJOINT, beta_sp, thr_sp,
+                                           z=z_list[l], g=v_list[l + 1], out1=dst,
+                                           out3=ustack[l][:N] if stacked else None, want_out3=loose)
+                if loose:
+                    wgrad.append((u_l, vb, dW[l]))
+            else:
+                # last layer: u = c * onehot(0).  c-bar = u-bar[:, 0] = v-bar W[0]^T;  W-bar[0] = c^T v-bar
+                # (both on the library's GEMM: torch.matmul would put a vendor GEMV and, for the row assignment,
+                #  a MEMCPY node into the captured iteration)
+                cb = gemm(vb, Ws[l][0:1], None, False, True)             # [N, 1]
+                if need_w[l]:
+                    gemm(c.reshape(N, 1), vb, None, True, False, out=dW[l][0:1], accumulate=True)
+
+    # ---- backward of the forward sweep (walks the layers downwards) ------------------------------------
+    # the weight gradients are independent of one another and of the rest of the sweep: they are collected and run as
+    # ONE grouped launch at the end (hm_gemm_f32_group_tn) instead of one split-K GEMM (+ its share of launches) per layer
+    zb = ops.sdf_head_bwd(d_out, sdf, c, denom, cb)
+    de = None
+    for l in range(L - 1, -1, -1):
+        if need_w[l]:
+            if ustack[l] is not None:                        # zb IS ustack[l][N:] (written by layer l+1 below)
+                wgrad.append((ustack[l], stack[l], dW[l]))                                  # [u; z-bar]^T [v-bar; a]
+            else:
+                wgrad.append((zb, a_list[l], dW[l]))
+        if need_b[l]:
+            bgrad.append((zb, db[l]))                        # column sums: one launch for all layers, below
+        if l > 0:
+            # a-bar_l = z-bar_l W_l; z-bar_{l-1} = a-bar_l[:, :dh] * s1(z_{l-1}) (+ the adjoint sweep's share)
+            dh = z_list[l - 1].shape[1]
+            is_skip = l == skip_layer
+            dst = ustack[l - 1][N:] if ustack[l - 1] is not None else None
+            ab, zb = gemm_ep(zb, Ws[l], None, False, False, EPI_S1MUL, beta_sp, thr_sp,
+                             scale=1.0 / _SQRT2 if is_skip else 1.0, z=z_list[l - 1], g=zx[l - 1], nz=dh,
+                             want_c=is_skip, out1=dst)
+            if is_skip:
+                de = ab[:, dh:] if de is None else de + ab[:, dh:]
+        else:
+            ab = gemm(zb, Ws[l], None, False, False)
+            de = ab if de is None else de + ab
+    gemm_group_tn(wgrad)
+    colsum_into_multi(bgrad)
+    d_e = de if need_e else None
+    return (d_e, *dW, *db)
 
 
-def sdf_mlp(e, weights, biases, skip_layer, beta_sp, thr_sp, beta_rho):
-    """(out [N, 1+fvs], d sdf/d e [N, E]); differentiable once w.r.t. e, weights and biases."""
+class _SdfMlpRows(torch.autograd.Function):
+    """The node of _SdfMlp for a ROW RANGE of a batch another _SdfMlp node has just evaluated with the SAME weights:
+    its forward results are that node's (out, g_e, z_l, a_l, v_l restricted to the rows), so nothing is recomputed; its
+    backward is the same analytic pass on the row slices.  IDRNetwork.forward_static evaluates the ray points twice -
+    once detached among the eikonal samples, once through SampleNetwork's re-parametrisation (the reference does it
+    four times, implicit_differentiable_renderer.py:264,286,289,321-323) - and the two inputs are the same numbers:
+    the second evaluation's 17 forward GEMMs disappear, its gradient flow (through its own embedding e2) is unchanged."""
+
+    @staticmethod
+    def forward(ctx, e2, cache, row0, n, *params):
+        L = cache["meta"][0]
+        sl = slice(int(row0), int(row0) + int(n))
+        cp = lambda t: ops.dcopy_(torch.empty_like(t), t)    # noqa: E731  (kernel copy: no MEMCPY graph node)
+        out = cp(cache["out"][sl])
+        g_e = cp(cache["g_e"][sl])
+        ctx.meta = cache["meta"]
+        Ws = params[:L]
+        if any(w.data_ptr() != cw.data_ptr() for w, cw in zip(Ws, cache["Ws"])):
+            raise RuntimeError("hashmod: _SdfMlpRows must see the weights of the evaluation it reuses")
+        ctx.save_for_backward(e2, cache["sdf"][sl], cache["c"][sl], cache["denom"][sl], *Ws,
+                              *[a[sl] for a in cache["a_list"]], *[z[sl] for z in cache["z_list"]],
+                              *[v[sl] for v in cache["v_list"]])
+        return out, g_e
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_out, d_ge):
+        L = ctx.meta[0]
+        grads = _sdf_mlp_backward(ctx.meta, ctx.saved_tensors, None, ctx.needs_input_grad[0],
+                                  ctx.needs_input_grad[4:4 + L], ctx.needs_input_grad[4 + L:4 + 2 * L], d_out, d_ge)
+        return (grads[0], None, None, None, *grads[1:])
+
+
+def sdf_mlp(e, weights, biases, skip_layer, beta_sp, thr_sp, beta_rho, cache_out=None):
+    """(out [N, 1+fvs], d sdf/d e [N, E]); differentiable once w.r.t. e, weights and biases.
+    cache_out: a dict that receives the evaluation's saved tensors (for sdf_mlp_rows)."""
     ops.require_gpu(e)
-    return _SdfMlp.apply(e.contiguous(), int(skip_layer), float(beta_sp), float(thr_sp), float(beta_rho),
+    return _SdfMlp.apply(e.contiguous(), int(skip_layer), float(beta_sp), float(thr_sp), float(beta_rho), cache_out,
                          *weights, *biases)
+
+
+def sdf_mlp_rows(e2, cache, row0, n, weights, biases):
+    """the same pair for rows [row0, row0 + n) of the batch `cache` was filled by (same weights, e2 == that batch's
+    embedding rows in value): no forward work, own backward (through e2)."""
+    ops.require_gpu(e2)
+    if e2.shape[0] != n or row0 < 0 or row0 + n > cache["out"].shape[0]:
+        raise ValueError("hashmod sdf_mlp_rows: row range does not match")
+    return _SdfMlpRows.apply(e2.contiguous(), cache, int(row0), int(n), *weights, *biases)
 
 
 class _ReluMlp(torch.autograd.Function):

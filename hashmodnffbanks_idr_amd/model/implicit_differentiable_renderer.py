@@ -240,9 +240,12 @@ class ImplicitNetwork(nn.Module):
         """d sdf / d x with the graph kept (create_graph=True) -> [N,1,3]."""
         return self.forward_with_gradient(x)[1]
 
-    def forward_with_gradient(self, x):
+    def forward_with_gradient(self, x, cache_out=None, reuse=None):
         """(forward(x) [N,1+fvs], d sdf/d x [N,1,3]) from ONE network evaluation; the reference
         evaluates the network twice for this pair (get_rbg_value, :321-323) with identical values.
+        cache_out (dict): receives the MLP node's saved tensors; reuse = (cache, row0, n): x holds the same numbers as
+        rows [row0, row0 + n) of the batch that filled `cache` in this forward pass - the MLP forward is not recomputed
+        (mlp_grad.sdf_mlp_rows), gradients flow through this call's own embedding as usual.
 
         Default route: the MLP and its input-gradient are one autograd node with an analytic backward
         (mlp_grad.sdf_mlp); only the embedding's Jacobian goes through autograd.  `use_fused_mlp_grad =
@@ -254,8 +257,11 @@ class ImplicitNetwork(nn.Module):
             Ws = [_folded_weight(lin, self._fold_cache) for lin in lins]
             bs = [lin.bias for lin in lins]
             skip = self.skip_in[0] if self.skip_in else -1
-            out, g_e = mlp_grad.sdf_mlp(e, Ws, bs, skip, self.softplus.beta, self.softplus.threshold,
-                                        self._beta_value())
+            if reuse is not None and reuse[0]:
+                out, g_e = mlp_grad.sdf_mlp_rows(e, reuse[0], reuse[1], reuse[2], Ws, bs)
+            else:
+                out, g_e = mlp_grad.sdf_mlp(e, Ws, bs, skip, self.softplus.beta, self.softplus.threshold,
+                                            self._beta_value(), cache_out=cache_out)
             if e is x:
                 g = g_e
             else:
@@ -347,6 +353,9 @@ class IDRNetwork(nn.Module):
         # one SDF-network evaluation per training forward instead of the reference's three (identical
         # values; only legal while the ray points carry no camera gradient - checked per call)
         self.merge_evaluations = True
+        # forward_static: the second SDF evaluation of the ray points reuses the first one's MLP forward (same inputs in
+        # value); False re-evaluates them (A/B, tests)
+        self.reuse_ray_rows = True
 
     def forward(self, input):
         cache = {}
@@ -489,7 +498,8 @@ class IDRNetwork(nn.Module):
             # of graph tensors (their autograd backward is zeros + a contiguous copy_ = a MEMCPY graph node)
             n_eik = eikonal_points.shape[0]
             x_all = torch.cat([eikonal_points, points.detach()], 0)
-            out_all, g_all = self.implicit_network.forward_with_gradient(x_all)
+            mlp_cache = {} if self.reuse_ray_rows else None
+            out_all, g_all = self.implicit_network.forward_with_gradient(x_all, cache_out=mlp_cache)
             grad_theta = g_all.reshape(-1, 3)
             sdf_output = ops.take_block(out_all, n_eik, n_rays, 0, 1)
             surface_mask = network_object_mask & object_mask
@@ -502,7 +512,9 @@ class IDRNetwork(nn.Module):
             t_theta = dists.unsqueeze(-1) - (sdf_output - sdf_output.detach()) / dot
             diff_points = cams + t_theta * ray_dirs
 
-            out2, g2 = self.implicit_network.forward_with_gradient(diff_points)
+            # diff_points holds the same numbers as `points` (t_theta = dists - 0 / dot): the second evaluation takes the
+            # first one's MLP results for those rows and keeps only its own gradient path (mlp_grad._SdfMlpRows)
+            out2, g2 = self.implicit_network.forward_with_gradient(diff_points, reuse=(mlp_cache, n_eik, n_rays))
             rgb = self.rendering_network(diff_points, g2.reshape(-1, 3), -ray_dirs, out2[:, 1:])
             rgb_values = torch.where(m, rgb, torch.ones_like(rgb))
             return {

@@ -180,3 +180,52 @@ def test_packed_weights_follow_graph_replays():
         if i >= 1:
             _sdf_matches_layerwise(net, x)
     assert stepper.g_fb is not None
+
+
+def test_static_step_reusing_the_ray_rows_equals_re_evaluating_them():
+    """IDRNetwork.forward_static evaluates the ray points twice (detached among the eikonal samples, then through
+    SampleNetwork's re-parametrisation); with reuse_ray_rows the second evaluation takes the first one's MLP forward
+    results (mlp_grad._SdfMlpRows).  The reused rows are bit-identical to the SAME rows of the big batch
+    (scripts/reuse_debug.py: 0.0), while a separate 512-row evaluation differs from them by an ulp (another GEMM tile
+    split: 1.2e-7 on out, 6e-8 on the gradient) - so outputs are compared to 2e-6 and gradients to 2e-5 of the
+    tensor's scale (order of the fp32 atomics of the weight-gradient accumulation included)."""
+    import bench
+    from helpers import idr_conf
+    from hashmodnffbanks_idr_amd.model.implicit_differentiable_renderer import IDRNetwork
+    from hashmodnffbanks_idr_amd.model.loss import idr_loss_terms
+    res = []
+    for reuse in (False, True):
+        torch.manual_seed(0)
+        model = IDRNetwork(idr_conf("C1")).cuda()
+        with torch.no_grad():
+            model.implicit_network.lin0.weight_v[:, 3:].normal_(0, 0.02)
+            model.implicit_network.embed_model.embedder_obj.table.uniform_(-0.05, 0.05)
+        model.train()
+        model.reuse_ray_rows = reuse
+        inp, gt = bench.synthetic_batch(7, 512, "cuda")
+        rs = np.random.RandomState(3)
+        inp["object_mask"] = torch.from_numpy(rs.uniform(0, 1, (1, 512)) < 0.8).cuda()
+        gt["rgb"] = torch.from_numpy(rs.uniform(-1, 1, (1, 512, 3)).astype(np.float32)).cuda()
+        g = torch.Generator().manual_seed(5)
+        steps = torch.empty(100).uniform_(0, 1, generator=g).cuda()
+        eik = torch.empty(256, 3).uniform_(-1, 1, generator=g).cuda()
+        out = model.forward_static(inp, eik, steps)
+        lo = idr_loss_terms(out, gt["rgb"], 0.1, 100.0, 50.0)
+        lo["loss"].backward()
+        res.append(({k: v.detach().clone() for k, v in out.items() if torch.is_tensor(v)}, lo["loss"].item(),
+                    {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}))
+    (o0, l0, g0), (o1, l1, g1) = res
+    for k in o0:
+        if o0[k].dtype.is_floating_point:
+            d = (o0[k] - o1[k]).abs().max().item()
+            assert d <= 2e-6 * max(1.0, o0[k].abs().max().item()), (k, d)
+        else:
+            assert torch.equal(o0[k], o1[k]), k
+    assert abs(l0 - l1) <= 2e-6 * abs(l0)
+    assert set(g0) == set(g1)
+    worst = 0.0
+    for n in g0:
+        scale = g0[n].abs().max().item() + 1e-30
+        worst = max(worst, (g0[n] - g1[n]).abs().max().item() / scale)
+    print(f"reuse of the ray rows: worst gradient difference / tensor scale {worst:.3e}")
+    assert worst <= 2e-5
