@@ -62,11 +62,28 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_kernel(HmLevels lv, Sd
     const int h = lane >> 5;
     const int L = lv.L, F = lv.F;
     const int E = lv.E;
-    const int64_t n_tiles = (n + kPts - 1) / kPts;
+    // Tile schedule: `rounds` full rounds of 64-point tiles (tile = round * grid + workgroup), then ONE remainder tile
+    // per workgroup.  When the remainder fits 32 points per workgroup it is cut into 32-point HALF tiles (the MFMAs of
+    // the second point block are skipped), so the last round costs about half a round instead of a full one on part of
+    // the chip: 204 800 points on 256 CUs are 12 rounds + 256 half tiles instead of 13 rounds on 128 CUs.  A point's
+    // value does not depend on the tile it sits in (tests: permutation equivariance bit for bit).
+    const int64_t G = gridDim.x;
+    const int64_t rounds = (n / kPts) / G;
+    const int64_t rem_base = rounds * G * kPts;
+    const int64_t rem_step = (n - rem_base <= G * 32) ? 32 : kPts;
 
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int64_t base = tile * kPts;
-        const int cnt = (int)min((int64_t)kPts, n - base);
+    for (int64_t it = 0; it <= rounds; ++it) {
+        int64_t base;
+        int cnt;
+        if (it < rounds) {
+            base = (it * G + blockIdx.x) * kPts;
+            cnt = kPts;
+        } else {
+            base = rem_base + (int64_t)blockIdx.x * rem_step;
+            if (base >= n) break;
+            cnt = (int)min(rem_step, n - base);
+        }
+        const bool half = cnt <= 32;   // (also a ragged last tile of <= 32 points)
         __syncthreads();  // previous tile's output stage is done with X
         if (FRAC != kFracEmb && tid < kPts * 3) SX[tid] = (tid < cnt * 3) ? x[base * 3 + tid] : 0.0f;
         __syncthreads();
@@ -207,23 +224,56 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_kernel(HmLevels lv, Sd
                 // whole groups of four octets run without an exit test: with a `break` inside the unrolled group
                 // hipcc cannot count the loads in flight across the back edge and drains them (vmcnt(0)) at every
                 // loop head; the 1-3 left-over octets are already in ring slots 0..2
+                // half tile: the same stream, point block 0 only (8 MFMAs per octet)
+                auto octet_h = [&](int gg, const float4 &a0, const float4 &a1) {
+                    const float *src = (gg < no0) ? src0 + (2 * gg + h) * kGroupFloats
+                                                  : src1 + (2 * (gg - no0) + h) * kGroupFloats;
+                    const float4 b0 = *reinterpret_cast<const float4 *>(src + j * 4);
+                    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc00, 0, 0, 0);
+                    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, acc10, 0, 0, 0);
+                    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc00, 0, 0, 0);
+                    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b0.y, acc10, 0, 0, 0);
+                    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc00, 0, 0, 0);
+                    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b0.z, acc10, 0, 0, 0);
+                    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc00, 0, 0, 0);
+                    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b0.w, acc10, 0, 0, 0);
+                };
                 const int n_full = n_oct & ~3;
-                for (int gg0 = 0; gg0 < n_full; gg0 += 4) {
+                if (!half) {
+                    for (int gg0 = 0; gg0 < n_full; gg0 += 4) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int gg = gg0 + u;
-                        {
-                            const size_t off = (size_t)min(gg + 3, n_oct - 1) * 64;
-                            r0[(u + 3) & 3] = A0[off];
-                            r1[(u + 3) & 3] = A1[off];
+                        for (int u = 0; u < 4; ++u) {
+                            const int gg = gg0 + u;
+                            {
+                                const size_t off = (size_t)min(gg + 3, n_oct - 1) * 64;
+                                r0[(u + 3) & 3] = A0[off];
+                                r1[(u + 3) & 3] = A1[off];
+                            }
+                            __builtin_amdgcn_sched_barrier(0);   // (loads stay ahead of this octet's MFMAs; see the 16-point body)
+                            octet(gg, r0[u], r1[u]);
                         }
-                        __builtin_amdgcn_sched_barrier(0);   // (loads stay ahead of this octet's MFMAs; see the 16-point body)
-                        octet(gg, r0[u], r1[u]);
                     }
+                    if (n_full + 0 < n_oct) octet(n_full + 0, r0[0], r1[0]);
+                    if (n_full + 1 < n_oct) octet(n_full + 1, r0[1], r1[1]);
+                    if (n_full + 2 < n_oct) octet(n_full + 2, r0[2], r1[2]);
+                } else {
+                    for (int gg0 = 0; gg0 < n_full; gg0 += 4) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int gg = gg0 + u;
+                            {
+                                const size_t off = (size_t)min(gg + 3, n_oct - 1) * 64;
+                                r0[(u + 3) & 3] = A0[off];
+                                r1[(u + 3) & 3] = A1[off];
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            octet_h(gg, r0[u], r1[u]);
+                        }
+                    }
+                    if (n_full + 0 < n_oct) octet_h(n_full + 0, r0[0], r1[0]);
+                    if (n_full + 1 < n_oct) octet_h(n_full + 1, r0[1], r1[1]);
+                    if (n_full + 2 < n_oct) octet_h(n_full + 2, r0[2], r1[2]);
                 }
-                if (n_full + 0 < n_oct) octet(n_full + 0, r0[0], r1[0]);
-                if (n_full + 1 < n_oct) octet(n_full + 1, r0[1], r1[1]);
-                if (n_full + 2 < n_oct) octet(n_full + 2, r0[2], r1[2]);
             }
             if (li + 1 < net.n_layers && !(li + 1 == net.n_layers - 1 && out_cols == 1) &&
                 net.layer[li + 1].n_tiles - 2 * wave > 0) {
@@ -257,11 +307,11 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_kernel(HmLevels lv, Sd
             };
             if (ntw > 0) {
                 store_tile(acc00, 0, 0);
-                store_tile(acc01, 0, 1);
+                if (!half) store_tile(acc01, 0, 1);
             }
             if (ntw > 1) {
                 store_tile(acc10, 1, 0);
-                store_tile(acc11, 1, 1);
+                if (!half) store_tile(acc11, 1, 1);
             }
             if (li == 0 && net.emb_groups > 0) {
                 // the skip layer consumes cat[x, emb]/sqrt(2): rescale the kept embedding once, in place
@@ -1228,7 +1278,7 @@ static int sdf_fwd_impl(const HmLevels &lv, const hm_mlp_desc *mlp, const float 
         const size_t lds = sizeof(float) * ((size_t)(net.x_groups + net.emb_groups) * kGroupFloats + kPts * 4 +
                                             kWaves * kPts);
         HM_CHECK_ARG(lds <= 160 * 1024, "hm_sdf_fwd: network does not fit the 160 KB LDS tile");
-        const int64_t tiles = (n + kPts - 1) / kPts;
+        const int64_t tiles = (n + 31) / 32;      // (up to cap * 32 points: one 32-point half tile per workgroup)
         const int64_t cap = max_workgroups > 0 ? max_workgroups : 256;
         const int64_t grid = tiles < cap ? tiles : cap;
         if (mode == kFracEmb)

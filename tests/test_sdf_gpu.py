@@ -345,6 +345,32 @@ def test_fused_forward_full_size_properties(golden, tile):
     _close(s[idx.cuda()].cpu().numpy(), ref[:, 0], what="sample vs oracle")
 
 
+@pytest.mark.parametrize("n", [37, 64 * 256 * 2 + 5000, 64 * 256 + 8192 + 64 * 3 + 1, 204800])
+def test_fused_forward_half_tile_schedule(golden, n):
+    """64-point kernel, tile schedule with 32-point half tiles for the remainder round (hm_sdf.hip: `half`): a point's
+    value must not depend on whether it sits in a full or a half tile - permutation equivariance bit for bit across the
+    two kinds (n = 2 full rounds + 157 half tiles; a remainder above 32 points per workgroup -> full tiles; the bench's
+    204 800 points = 12 rounds + 256 half tiles; 37 points = one full-width ragged tile), and the values against the
+    16-point kernel's (another MFMA shape: tolerance, not bits)."""
+    g = golden("sdf_C2")
+    net = _net(g, "C2")
+    gen = torch.Generator(device="cpu").manual_seed(5 + n)
+    x = (torch.rand((n, 3), generator=gen) * 2.1 - 1.05).cuda()
+    perm = torch.randperm(n, generator=gen).cuda()
+    with torch.no_grad():
+        net.sdf_tile_points = 64
+        s = net.sdf(x)
+        sp = net.sdf(x[perm].contiguous())
+        full = net(x[:4096].contiguous()) if n >= 4096 else None
+        net.sdf_tile_points = 16
+        s16 = net.sdf(x[: min(n, 20000)].contiguous())
+    assert torch.equal(sp, s[perm])
+    _close(s[: s16.shape[0]].cpu().numpy(), s16.cpu().numpy(), what="64-point schedule vs 16-point tiles")
+    if full is not None:
+        # all output columns (last layer on the MFMA instead of the sdf-only VALU dot): same schedule, 128 half tiles
+        _close(full[:, 0].cpu().numpy(), s[:4096].reshape(-1).cpu().numpy(), what="full output vs sdf-only")
+
+
 def test_relu_mlp_node_matches_generic_ops():
     """mlp_grad.relu_mlp (rendering network's Linear / ReLU stack as one autograd node with ReLU GEMM epilogues)
     against the same stack on torch ops: output and first-order gradients w.r.t. input, weights and biases."""
