@@ -88,6 +88,7 @@ class _SdfMlp(torch.autograd.Function):
         ctx.meta = (L, skip_layer, beta_sp, thr_sp, E)
         ctx.stack = stack      # internal buffers (their lower halves are the saved a_l views)
         ctx.save_for_backward(e, sdf, c, denom, *Ws, *a_list, *z_list, *v_list)
+        ctx.shared = cache_out        # (weight / bias gradient accumulators shared with a _SdfMlpRows node, see there)
         if cache_out is not None:     # lets a second node over a ROW RANGE of this batch skip its forward (_SdfMlpRows)
             cache_out.update(meta=ctx.meta, out=out, g_e=g_e, sdf=sdf, c=c, denom=denom, a_list=a_list, z_list=z_list,
                              v_list=v_list, Ws=Ws)
@@ -98,14 +99,20 @@ class _SdfMlp(torch.autograd.Function):
     def backward(ctx, d_out, d_ge):
         L = ctx.meta[0]
         grads = _sdf_mlp_backward(ctx.meta, ctx.saved_tensors, ctx.stack, ctx.needs_input_grad[0],
-                                  ctx.needs_input_grad[6:6 + L], ctx.needs_input_grad[6 + L:6 + 2 * L], d_out, d_ge)
+                                  ctx.needs_input_grad[6:6 + L], ctx.needs_input_grad[6 + L:6 + 2 * L], d_out, d_ge,
+                                  shared=ctx.shared, owner=True)
         return (grads[0], None, None, None, None, None, *grads[1:])
 
 
-def _sdf_mlp_backward(meta, sv, stack, need_e, need_w, need_b, d_out, d_ge):
+def _sdf_mlp_backward(meta, sv, stack, need_e, need_w, need_b, d_out, d_ge, shared=None, owner=True):
     """Analytic reverse-over-reverse of the forward sweep and the gradient sweep (see the module docstring).
     stack: the forward's [2N, in_l] buffers (weight gradients as ONE stacked product per layer), or None (a node that
-    reuses another node's saved activations, _SdfMlpRows: u^T v-bar and z-bar^T a are two entries of the grouped launch)."""
+    reuses another node's saved activations, _SdfMlpRows: u^T v-bar and z-bar^T a are two entries of the grouped launch).
+    shared / owner: two nodes over the SAME weights (the evaluation and its _SdfMlpRows companion) accumulate their
+    weight / bias gradients into ONE set of buffers kept in the dict `shared`: the companion (owner = False; its
+    backward always runs first - its input depends on the owner's output) allocates and zeroes them and returns no
+    weight gradients, the owner adds its own share and returns the sums - autograd then has nothing to add up (18
+    elementwise launches per step) and the buffers are zeroed once."""
     L, skip_layer, beta_sp, thr_sp, E = meta
     e, sdf, c, denom = sv[0], sv[1], sv[2], sv[3]
     Ws = sv[4:4 + L]
@@ -118,11 +125,21 @@ def _sdf_mlp_backward(meta, sv, stack, need_e, need_w, need_b, d_out, d_ge):
     # every weight / bias gradient accumulates with atomics (grouped GEMM, column sums): the buffers are zeroed
     # here by ONE multi-tensor launch instead of one zeroing launch in front of each producer
     bshape = [z.shape[1] for z in z_list]
-    dW = [torch.empty_like(Ws[l]) if need_w[l] else None for l in range(L)]
-    db = [torch.empty(bshape[l], dtype=torch.float32, device=e.device) if need_b[l] else None for l in range(L)]
-    zero_list = [t for t in dW + db if t is not None]
-    if zero_list:
-        torch._foreach_zero_(zero_list)
+    acc = shared.pop("wgrad_acc", None) if (shared is not None and owner) else None
+    if acc is not None and acc[2] == (tuple(bool(w) for w in need_w), tuple(bool(b) for b in need_b)):
+        dW, db = acc[0], acc[1]          # the companion's sums: this pass adds to them
+    else:
+        dW = [torch.empty_like(Ws[l]) if need_w[l] else None for l in range(L)]
+        db = [torch.empty(bshape[l], dtype=torch.float32, device=e.device) if need_b[l] else None for l in range(L)]
+        zero_list = [t for t in dW + db if t is not None]
+        if zero_list:
+            torch._foreach_zero_(zero_list)
+        if acc is not None:              # (different gradient sets on the two nodes: not the static step; add up here)
+            for l in range(L):
+                if dW[l] is not None and acc[0][l] is not None:
+                    dW[l].add_(acc[0][l])
+                if db[l] is not None and acc[1][l] is not None:
+                    db[l].add_(acc[1][l])
     zx = [None] * L       # extra z-bar from the adjoint of the gradient sweep
     ustack = [None] * L   # [u_l; z-bar_l] of the layers whose weight gradient is one stacked GEMM
     cb = None
@@ -191,6 +208,10 @@ def _sdf_mlp_backward(meta, sv, stack, need_e, need_w, need_b, d_out, d_ge):
     gemm_group_tn(wgrad)
     colsum_into_multi(bgrad)
     d_e = de if need_e else None
+    if shared is not None and not owner:
+        # hand the sums to the owner's backward pass; autograd sees no weight gradient from this node
+        shared["wgrad_acc"] = (dW, db, (tuple(bool(w) for w in need_w), tuple(bool(b) for b in need_b)))
+        return (d_e, *([None] * (2 * L)))
     return (d_e, *dW, *db)
 
 
@@ -210,6 +231,7 @@ class _SdfMlpRows(torch.autograd.Function):
         out = cp(cache["out"][sl])
         g_e = cp(cache["g_e"][sl])
         ctx.meta = cache["meta"]
+        ctx.shared = cache            # weight / bias gradients are accumulated with the owner's (_sdf_mlp_backward)
         Ws = params[:L]
         if any(w.data_ptr() != cw.data_ptr() for w, cw in zip(Ws, cache["Ws"])):
             raise RuntimeError("hashmod: _SdfMlpRows must see the weights of the evaluation it reuses")
@@ -223,7 +245,8 @@ class _SdfMlpRows(torch.autograd.Function):
     def backward(ctx, d_out, d_ge):
         L = ctx.meta[0]
         grads = _sdf_mlp_backward(ctx.meta, ctx.saved_tensors, None, ctx.needs_input_grad[0],
-                                  ctx.needs_input_grad[4:4 + L], ctx.needs_input_grad[4 + L:4 + 2 * L], d_out, d_ge)
+                                  ctx.needs_input_grad[4:4 + L], ctx.needs_input_grad[4 + L:4 + 2 * L], d_out, d_ge,
+                                  shared=ctx.shared, owner=False)
         return (grads[0], None, None, None, *grads[1:])
 
 

@@ -20,10 +20,65 @@ from .. import _lib
 from ..model.loss import idr_loss_terms
 
 
+class LocalTableGrad:
+    """``emb.grad_collector`` of the single-process static step: every table backward of an iteration (the eikonal /
+    ray-point evaluation, the re-parametrised ray points, a view-direction grid) scatters into ONE dense gradient that is
+    bound as ``table.grad`` and zeroed once per step.  Plain autograd gives each scatter node a ``zeros_like(table)`` of
+    its own and adds the dense results up: 3 fills + 2 adds over 40 MB (T = 2^19) / 224 MB (T = 2^22) per step.
+    Same protocol as parallel.TouchedRowExchange (begin_step / attach / add), without the row lists; reference frac
+    mode only, for the reason given there."""
+
+    def __init__(self, emb):
+        if emb.frac_mode != "reference":
+            raise NotImplementedError("LocalTableGrad: frac_mode='trilinear' keeps autograd's dense accumulation")
+        self.emb, self.param = emb, emb.table
+        self.active = False
+        self.dense = torch.zeros_like(emb.table)
+        emb.grad_collector = self
+
+    def begin_step(self):
+        self.active = True          # (only while the stepper's own forward / backward runs: other users of the model -
+        self.dense.zero_()          #  eager steps, tests - keep autograd's table gradient)   [zero_ = a fill kernel]
+
+    def end_step(self):
+        self.active = False
+
+    def attach(self):
+        self.param.grad = self.dense
+
+    def add(self, x, d_feat):
+        from .. import ops
+        if self.param.grad is None:
+            self.param.grad = self.dense
+        elif self.param.grad.data_ptr() != self.dense.data_ptr():
+            raise RuntimeError("LocalTableGrad: table.grad was re-bound; call attach() after zero_grad()")
+        ops.encode_bwd_table(self.emb.desc, x.detach().reshape(-1, 3), d_feat.detach(), 0, out=self.dense)
+
+    def release(self):
+        if self.emb.grad_collector is self:
+            self.emb.grad_collector = None
+
+
+def local_table_grads(model):
+    """LocalTableGrad for every reference-mode hash grid of the model that has no gradient collector yet"""
+    out = []
+    for net in (model.implicit_network, model.rendering_network):
+        emb = getattr(getattr(net, "embed_model", None), "embedder_obj", None)
+        emb = getattr(emb, "grid_enc", emb)          # filter-bank embedders own a hash grid too
+        if (emb is not None and hasattr(emb, "grad_collector") and emb.grad_collector is None
+                and getattr(emb, "frac_mode", None) == "reference" and emb.table.requires_grad):
+            out.append(LocalTableGrad(emb))
+    return out
+
+
 class GraphedTrainStep:
     def __init__(self, model, loss_fn, optimizer, reducer=None, max_norm=1.0, warmup=3, use_graph=True,
                  sync_each_step=None):
         self.model, self.loss_fn, self.opt, self.reducer = model, loss_fn, optimizer, reducer
+        # single process: the hash tables' gradients accumulate in one static dense tensor each (LocalTableGrad);
+        # HM_LOCAL_TABLE_GRAD=0 keeps autograd's per-node dense gradients (A/B)
+        self.local_tables = (local_table_grads(model)
+                             if reducer is None and os.environ.get("HM_LOCAL_TABLE_GRAD", "1") != "0" else [])
         self.max_norm, self.warmup_left, self.use_graph = max_norm, warmup, use_graph
         self.static_exchange = reducer is not None and hasattr(reducer, "pack")   # parallel.StaticGradExchange
         if self.static_exchange and reducer.opt is None:
@@ -70,7 +125,7 @@ class GraphedTrainStep:
         return steps, eik, ev
 
     def _sparse(self):
-        return getattr(self.reducer, "sparse", ()) if self.reducer is not None else ()
+        return getattr(self.reducer, "sparse", ()) if self.reducer is not None else self.local_tables
 
     def _fwd_bwd(self):
         for ex in self._sparse():
@@ -81,6 +136,8 @@ class GraphedTrainStep:
         out = self.model.forward_static(s["input"], s["eik"], s["steps"])
         lo = idr_loss_terms(out, s["rgb"], self.loss_fn.eikonal_weight, self.loss_fn.mask_weight, self.loss_fn.alpha)
         lo["loss"].backward()
+        for ex in self.local_tables:
+            ex.end_step()
         if self.static_exchange:
             self.reducer.pack()          # payloads + flat bucket: kernels, part of the captured forward/backward graph
         return out, lo
@@ -108,6 +165,8 @@ class GraphedTrainStep:
 
     def _eager_iteration(self):
         self.opt.zero_grad(set_to_none=True)
+        for ex in self.local_tables:
+            ex.attach()
         if self.static_exchange:
             self.reducer.attach()
         out, lo = self._fwd_bwd()
