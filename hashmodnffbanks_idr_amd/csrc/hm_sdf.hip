@@ -28,6 +28,7 @@
 namespace {
 
 #include "hm_sdf_common.h"
+#include "hm_trace_dev.h"   // the ray search's state machine, run by the persistent march kernel below
 
 // third value of the kernels' FRAC template parameter: `x` holds PRECOMPUTED embedding rows (hm_sdf_fwd_emb).  A template
 // value rather than a run-time branch on net.emb_stride: with both input paths in one kernel body the register
@@ -581,7 +582,8 @@ template <int FRAC>
 __device__ __forceinline__ void sdf_m16_body(const HmLevels &lv, const SdfNet &net, const float *__restrict__ x,
                                              int64_t n, const float *__restrict__ table,
                                              const float *__restrict__ Bf, float *__restrict__ out,
-                                             int64_t out_stride, int out_cols, float *lds) {
+                                             int64_t out_stride, int out_cols, float *lds, int64_t tile_first,
+                                             int64_t tile_step) {
     const int emb_groups16 = ((lv.E + 15) / 16) * 4;
     float *X = lds;
     float *EMB = lds + (size_t)net.x_groups * kGroupFloats16;
@@ -596,7 +598,7 @@ __device__ __forceinline__ void sdf_m16_body(const HmLevels &lv, const SdfNet &n
     const int L = lv.L, F = lv.F, E = lv.E;
     const int64_t n_tiles = (n + kPts16 - 1) / kPts16;
 
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (int64_t tile = tile_first; tile < n_tiles; tile += tile_step) {
         const int64_t base = tile * kPts16;
         const int cnt = (int)min((int64_t)kPts16, n - base);
         __syncthreads();
@@ -823,7 +825,8 @@ template <int FRAC, int PTS>
 __device__ __forceinline__ void sdf_m8_body(const HmLevels &lv, const SdfNet &net, const float *__restrict__ x,
                                             int64_t n, const float *__restrict__ table,
                                             const float *__restrict__ Bf, float *__restrict__ out,
-                                            int64_t out_stride, int out_cols, float *lds) {
+                                            int64_t out_stride, int out_cols, float *lds, int64_t tile_first,
+                                            int64_t tile_step) {
     const int emb_groups16 = ((lv.E + 15) / 16) * 4;
     float *X = lds;
     float *EMB = lds + (size_t)net.x_groups * kGroupFloats8;
@@ -841,7 +844,7 @@ __device__ __forceinline__ void sdf_m8_body(const HmLevels &lv, const SdfNet &ne
     constexpr int RD8 = kRing8;   // (one block deeper for the 4-point variant measured the same: 94 vs 93 us)
     const int64_t n_tiles = (n + PTS - 1) / PTS;
 
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (int64_t tile = tile_first; tile < n_tiles; tile += tile_step) {
         const int64_t base = tile * PTS;
         const int cnt = (int)min((int64_t)PTS, n - base);
         __syncthreads();
@@ -1082,11 +1085,62 @@ __global__ __launch_bounds__(kThreadsSdf, 1) void sdf_fwd_small_kernel(HmLevels 
     if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));
     if (n < run_min || n > run_max) return;
     if (n <= m4_max)
-        sdf_m8_body<FRAC, 4>(lv, net, x, n, table, Bf, out, out_stride, out_cols, lds);
+        sdf_m8_body<FRAC, 4>(lv, net, x, n, table, Bf, out, out_stride, out_cols, lds, blockIdx.x, gridDim.x);
     else if (n <= m8_max)
-        sdf_m8_body<FRAC, 8>(lv, net, x, n, table, Bf, out, out_stride, out_cols, lds);
+        sdf_m8_body<FRAC, 8>(lv, net, x, n, table, Bf, out, out_stride, out_cols, lds, blockIdx.x, gridDim.x);
     else
-        sdf_m16_body<FRAC>(lv, net, x, n, table, Bf, out, out_stride, out_cols, lds);
+        sdf_m16_body<FRAC>(lv, net, x, n, table, Bf, out, out_stride, out_cols, lds, blockIdx.x, gridDim.x);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Persistent sphere-tracing march (reference: model/ray_tracing.py:98-187): a workgroup owns EIGHT rays - at most 16
+// pending points, the start and the end of each - and carries them through ALL rounds of the state machine: evaluate
+// the pending points with the small-tile body that fits their number (16 / 8 / 4 points), run trace_advance_ray for
+// its own rays, repeat until every one of them is done.  Rays are independent, so nothing is exchanged between
+// workgroups and nothing synchronises the grid: the 41 (SDF launch, update launch) pairs the launch-per-round search
+// enqueues - 30 of them empty whenever no ray needs a line search - become ONE launch, and a workgroup whose rays
+// have converged leaves.  The pending points live in the workgroup's own 16 slots of pts / vals (cursor in LDS).
+// Every round runs on the 16-point body: the march's SDF values are bit-identical to hm_sdf_fwd with tile_points = 16
+// (the rule the generic tracer follows for its march rounds, model/ray_tracing.py).  The 8- / 4-point bodies for
+// workgroups with few live points were tried here: with them inlined beside the 16-point body the kernel needs more than
+// 256 registers and the weight rings spill (58 - 88 spilled VGPRs).
+// (out of line: inlined into the kernel the state machine's registers are live across the three tile bodies, which
+//  sit at the 256-register limit already, and the weight rings spill)
+__device__ __attribute__((noinline)) void march_init_ray(const TraceArgs &a, int64_t ray, int32_t *cursor, int32_t slot_base) {
+    trace_init_ray(a, ray, cursor, slot_base);
+}
+__device__ __attribute__((noinline)) void march_advance_ray(const TraceArgs &a, int64_t ray, int32_t *cursor, int32_t slot_base) {
+    trace_advance_ray(a, ray, cursor, slot_base);
+}
+
+template <int FRAC>
+__global__ __launch_bounds__(kThreadsSdf, 1) void trace_march_kernel(HmLevels lv, SdfNet net,
+                                                                      const float *__restrict__ table,
+                                                                      const float *__restrict__ Bf, TraceArgs a,
+                                                                      int rounds, int lds_floats) {
+    extern __shared__ __align__(16) float lds[];
+    int32_t *ctl = reinterpret_cast<int32_t *>(lds + lds_floats);   // [0] cursor of the round being filled
+    const int tid = threadIdx.x;
+    const int32_t slot_base = (int32_t)blockIdx.x * 16;
+    const int64_t ray = (int64_t)blockIdx.x * 8 + tid;
+    const bool mine = tid < 8 && ray < a.n;
+    const float *xp = a.w.pts + (int64_t)slot_base * 3;
+    float *vp = a.w.vals + slot_base;
+    if (tid == 0) ctl[0] = 0;
+    __syncthreads();
+    if (mine) march_init_ray(a, ray, ctl, slot_base);
+    __syncthreads();
+    for (int r = 0; r < rounds; ++r) {
+        const int n_loc = ctl[0];
+        if (n_loc == 0) break;      // (uniform) every ray of this workgroup is done
+        if (tid == 0) atomicAdd(a.w.cnt + C_ROUND0 + r, n_loc);     // the search's evaluation count (statistics)
+        sdf_m16_body<FRAC>(lv, net, xp, n_loc, table, Bf, vp, 1, 1, lds, 0, 1 << 30);
+        __syncthreads();            // the values (global stores of this workgroup) are visible to its threads
+        if (tid == 0) ctl[0] = 0;
+        __syncthreads();
+        if (mine) march_advance_ray(a, ray, ctl, slot_base);
+        __syncthreads();
+    }
 }
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
@@ -1119,26 +1173,17 @@ int hm_sdf_fwd_emb(const hm_mlp_desc *mlp, const float *emb, int64_t emb_stride,
                         tile_points, n_dev, max_workgroups, stream);
 }
 
-static int sdf_fwd_impl(const HmLevels &lv, const hm_mlp_desc *mlp, const float *x, int64_t emb_stride, int64_t n,
-                        const float *table, const float *B_fourier, float *out, int64_t out_stride, int out_cols,
-                        int frac_mode, int tile_points, const int32_t *n_dev, int max_workgroups, void *stream) {
-    HM_CHECK_ARG(mlp, "hm_sdf_fwd: NULL descriptor");
-    HM_CHECK_ARG(n >= 0, "hm_sdf_fwd: n < 0");
-    HM_CHECK_ARG(frac_mode == HM_FRAC_REFERENCE || frac_mode == HM_FRAC_TRILINEAR, "hm_sdf_fwd: bad frac_mode");
-    HM_CHECK_ARG(mlp->n_layers >= 1 && mlp->n_layers <= HM_MAX_LAYERS, "hm_sdf_fwd: n_layers out of range");
-    HM_CHECK_ARG(tile_points == 0 || tile_points == 4 || tile_points == 8 || tile_points == 16 || tile_points == 32 ||
-                     tile_points == 64 || tile_points == -1,
-                 "hm_sdf_fwd: tile_points must be -1, 0, 4, 8, 16, 32 or 64");
-    SdfNet net;
+// kernel-side image of the network descriptor (+ the checks every fused SDF launch makes on it)
+static int sdf_net_from_desc(const HmLevels &lv, const hm_mlp_desc *mlp, int64_t emb_stride, SdfNet &net, bool &have16) {
+    HM_CHECK_ARG(mlp && mlp->n_layers >= 1 && mlp->n_layers <= HM_MAX_LAYERS, "hm_sdf_fwd: n_layers out of range");
     net.n_layers = mlp->n_layers;
     net.beta = mlp->beta;
     net.emb_stride = emb_stride;
-    const int mode = emb_stride > 0 ? kFracEmb : frac_mode;    // kernel template value
     const int emb_oct = (lv.E + 7) / 8;
     const int emb_b16 = (lv.E + 15) / 16;
     net.emb_groups = emb_oct * 2;
     int x_groups = 0;
-    bool have16 = true;
+    have16 = true;
     for (int l = 0; l < mlp->n_layers; ++l) {
         const hm_mlp_layer &Ly = mlp->layer[l];
         HM_CHECK_ARG(Ly.w_packed && Ly.bias, "hm_sdf_fwd: layer has NULL weights/bias");
@@ -1167,6 +1212,57 @@ static int sdf_fwd_impl(const HmLevels &lv, const hm_mlp_desc *mlp, const float 
         net.layer[l] = Ly;
     }
     net.x_groups = x_groups;
+    return HM_OK;
+}
+
+// internal entry of the ray search (hm_trace.hip, not exported): the whole sphere-tracing march as ONE launch
+// (trace_march_kernel).  `trace_args` = a TraceArgs of hm_trace_dev.h; the caller has zeroed its counters.
+int hm_trace_march_persistent(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *table,
+                              const float *B_fourier, int frac_mode, const void *trace_args, int rounds,
+                              void *stream) {
+    HM_CHECK_ARG(desc && mlp && table && B_fourier && trace_args, "hm_trace_march_persistent: NULL argument");
+    HM_CHECK_ARG(frac_mode == HM_FRAC_REFERENCE || frac_mode == HM_FRAC_TRILINEAR, "hm_trace_march_persistent: bad frac_mode");
+    const TraceArgs &a = *static_cast<const TraceArgs *>(trace_args);
+    SdfNet net;
+    bool have16 = false;
+    const int rc = sdf_net_from_desc(desc->lv, mlp, 0, net, have16);
+    if (rc != HM_OK) return rc;
+    HM_CHECK_ARG(have16, "hm_trace_march_persistent: needs w_packed_m16 in every layer");
+    if (a.n == 0) return HM_OK;
+    HM_CHECK_ARG(a.w.cap >= ((a.n + 7) / 8) * 16, "hm_trace_march_persistent: point buffer too small");
+    const int emb_b16 = (desc->lv.E + 15) / 16;
+    const int lds_floats = (net.x_groups + emb_b16 * 4) * kGroupFloats16 + kPts16 * 4 + kWaves * kPts16;
+    const size_t lds = sizeof(float) * (size_t)lds_floats + 64;
+    HM_CHECK_ARG(lds <= 64 * 1024, "hm_trace_march_persistent: network does not fit the 16-point LDS tile");
+    const unsigned grid = (unsigned)((a.n + 7) / 8);
+    if (frac_mode == HM_FRAC_REFERENCE)
+        hipLaunchKernelGGL(trace_march_kernel<HM_FRAC_REFERENCE>, dim3(grid), dim3(kThreadsSdf), lds, as_stream(stream),
+                           desc->lv, net, table, B_fourier, a, rounds, lds_floats);
+    else
+        hipLaunchKernelGGL(trace_march_kernel<HM_FRAC_TRILINEAR>, dim3(grid), dim3(kThreadsSdf), lds, as_stream(stream),
+                           desc->lv, net, table, B_fourier, a, rounds, lds_floats);
+    HM_CHECK_LAUNCH("hm_trace_march_persistent");
+    return HM_OK;
+}
+
+static int sdf_fwd_impl(const HmLevels &lv, const hm_mlp_desc *mlp, const float *x, int64_t emb_stride, int64_t n,
+                        const float *table, const float *B_fourier, float *out, int64_t out_stride, int out_cols,
+                        int frac_mode, int tile_points, const int32_t *n_dev, int max_workgroups, void *stream) {
+    HM_CHECK_ARG(mlp, "hm_sdf_fwd: NULL descriptor");
+    HM_CHECK_ARG(n >= 0, "hm_sdf_fwd: n < 0");
+    HM_CHECK_ARG(frac_mode == HM_FRAC_REFERENCE || frac_mode == HM_FRAC_TRILINEAR, "hm_sdf_fwd: bad frac_mode");
+    HM_CHECK_ARG(mlp->n_layers >= 1 && mlp->n_layers <= HM_MAX_LAYERS, "hm_sdf_fwd: n_layers out of range");
+    HM_CHECK_ARG(tile_points == 0 || tile_points == 4 || tile_points == 8 || tile_points == 16 || tile_points == 32 ||
+                     tile_points == 64 || tile_points == -1,
+                 "hm_sdf_fwd: tile_points must be -1, 0, 4, 8, 16, 32 or 64");
+    SdfNet net;
+    bool have16 = true;
+    {
+        const int rc = sdf_net_from_desc(lv, mlp, emb_stride, net, have16);
+        if (rc != HM_OK) return rc;
+    }
+    const int mode = emb_stride > 0 ? kFracEmb : frac_mode;    // kernel template value
+    const int emb_b16 = (lv.E + 15) / 16;
     const hm_mlp_layer &last = mlp->layer[mlp->n_layers - 1];
     HM_CHECK_ARG(out_cols == 1 || out_cols == last.out_dim, "hm_sdf_fwd: out_cols must be 1 or the last layer's out_dim");
     HM_CHECK_ARG(out_stride >= out_cols, "hm_sdf_fwd: out_stride < out_cols");

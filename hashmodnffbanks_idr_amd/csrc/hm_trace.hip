@@ -15,174 +15,32 @@
 // is compiled with -ffp-contract=off.
 #include "hm_common.h"
 
+#include <stdlib.h>
+
+// hm_sdf.hip (not exported): the whole sphere-tracing march as one persistent launch
+extern "C" int hm_trace_march_persistent(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *table,
+                                         const float *B_fourier, int frac_mode, const void *trace_args, int rounds,
+                                         void *stream);
+
 namespace {
 
 constexpr int kTB = 256;
 
-enum : int32_t {  // counters (device int32 array)
-    C_ROUND0 = 0,        // [0..63] points appended in march round r
-    C_NSAMP = 64,        // rays handed to the sampler
-    C_NSAMP_PTS = 65,    // C_NSAMP * n_steps
-    C_NSEC = 66,         // rays in the secant refinement
-    C_NSEL = 67,         // mask-loss rays for the closest-approach search
-    C_NSEL_PTS = 68,
-    C_ANY_LIVE = 69,     // some ray was still marching after the first evaluation (=> >= 1 global iteration)
-    C_EVALS = 70,        // total SDF point evaluations (statistics)
-    C_UNFINISHED = 71,   // rays whose state machine had not finished after the last march round
-    C_BIG_PTS = 73,      // points of the one big SDF launch: sampler points followed by closest-approach points
-    C_NONFINITE = 72,    // SDF values consumed by the search that were NaN / Inf (must be 0: a NaN fails every
-                         // `sdf > threshold` test, so the ray would silently count as converged where it stands)
-    C_NSAMP2 = 74,       // lazy sampler: rays whose first sign change is not among the head samples
-    C_HEAD_PTS = 75,     // points of the sampler's first pass (= where the closest-approach values start)
-    C_TAIL_PTS = 76,     // lazy sampler: points of the second pass
-    C_COUNT = 80
-};
-
-enum : uint8_t { ST_WAIT_FIRST = 1, ST_WAIT_MARCH = 2, ST_WAIT_LS = 3, ST_DONE = 4 };
-
-struct TraceWs {
-    float *t_s, *t_e, *t_min, *t_max, *cur_s, *cur_e, *nxt_s, *nxt_e;  // [N]
-    float *z_lo, *z_hi, *v_lo, *v_hi, *z;                               // [N] secant state by secant slot
-    int32_t *slot_s, *slot_e, *list_samp, *list_sec, *list_sel;          // [N]
-    int32_t *tail_slot;      // [N] by sampler slot: index in the second pass, -1 = resolved by the head samples
-    uint8_t *live_s, *live_e, *stage, *it, *k, *is_samp;                // [N]
-    float *pts;    // [cap,3]
-    float *vals;   // [cap]
-    int32_t *cnt;  // [C_COUNT]
-    int64_t cap;
-};
-
-struct TraceArgs {
-    TraceWs w;
-    const float *cam;        // [B,3]
-    const float *dirs;       // [N,3]
-    const uint8_t *obj;      // [N]
-    const float *t_sphere;   // [N,2]
-    const uint8_t *hit;      // [N]
-    const float *fracs;      // [n_steps] linspace(0,1)
-    const float *steps_u;    // [n_steps] shared random fractions (training tail)
-    float *out_pts;          // [N,3]
-    uint8_t *out_mask;       // [N]
-    float *out_t;            // [N]
-    int64_t n, rays_per_image;
-    float thr;
-    float back[4];           // (1 - line_search_step) / 2^k, formed in double on the host
-    int32_t ls_iters, max_it, n_steps, n_secant, training;
-    int32_t head;            // lazy sampler: samples 0..head-1 and n_steps-1 form the first pass (0 = all in one pass)
-    int64_t tail_off;        // lazy sampler: where the second pass starts in pts / vals (host-known: the buffers are
-                             // sized for 2 * N * n_steps points)
-};
-
-__device__ __forceinline__ void along(const TraceArgs &a, int64_t i, float t, float &px, float &py, float &pz) {
-    const float *c = a.cam + (i / a.rays_per_image) * 3;
-    const float *d = a.dirs + i * 3;
-    px = __fadd_rn(c[0], __fmul_rn(t, d[0]));
-    py = __fadd_rn(c[1], __fmul_rn(t, d[1]));
-    pz = __fadd_rn(c[2], __fmul_rn(t, d[2]));
-}
-
-__device__ __forceinline__ int32_t append_point(const TraceArgs &a, int32_t *cursor, int64_t i, float t) {
-    const int32_t idx = atomicAdd(cursor, 1);
-    float px, py, pz;
-    along(a, i, t, px, py, pz);
-    a.w.pts[(int64_t)idx * 3 + 0] = px;
-    a.w.pts[(int64_t)idx * 3 + 1] = py;
-    a.w.pts[(int64_t)idx * 3 + 2] = pz;
-    return idx;
-}
+#include "hm_trace_dev.h"
 
 // round 0: both sphere intersections of every ray that hits the bounding sphere (ray_tracing.py:101-128)
 __global__ __launch_bounds__(kTB) void trace_init_kernel(TraceArgs a) {
     const int64_t i = (int64_t)blockIdx.x * kTB + threadIdx.x;
     if (i >= a.n) return;
-    const TraceWs &w = a.w;
-    const bool hit = a.hit[i] != 0;
-    const float ts = hit ? a.t_sphere[2 * i] : 0.0f, te = hit ? a.t_sphere[2 * i + 1] : 0.0f;
-    w.t_s[i] = ts; w.t_e[i] = te; w.t_min[i] = ts; w.t_max[i] = te;
-    w.cur_s[i] = 0.0f; w.cur_e[i] = 0.0f; w.nxt_s[i] = 0.0f; w.nxt_e[i] = 0.0f;
-    w.live_s[i] = hit; w.live_e[i] = hit;
-    w.it[i] = 0; w.k[i] = 0; w.is_samp[i] = 0;
-    w.stage[i] = ST_WAIT_FIRST;
-    w.slot_s[i] = hit ? append_point(a, w.cnt + C_ROUND0, i, ts) : -1;
-    w.slot_e[i] = hit ? append_point(a, w.cnt + C_ROUND0, i, te) : -1;
+    trace_init_ray(a, i, a.w.cnt + C_ROUND0, 0);
 }
 
-// one round of the per-ray sphere-tracing state machine (ray_tracing.py:130-186)
+// one round of the per-ray sphere-tracing state machine (ray_tracing.py:130-186): the points it appends are evaluated
+// by the next round's SDF launch
 __global__ __launch_bounds__(kTB) void trace_advance_kernel(TraceArgs a, int round) {
     const int64_t i = (int64_t)blockIdx.x * kTB + threadIdx.x;
     if (i >= a.n) return;
-    const TraceWs &w = a.w;
-    uint8_t st = w.stage[i];
-    if (st == ST_DONE) return;
-    float t_s = w.t_s[i], t_e = w.t_e[i], cur_s = w.cur_s[i], cur_e = w.cur_e[i];
-    float nxt_s = w.nxt_s[i], nxt_e = w.nxt_e[i];
-    bool live_s = w.live_s[i], live_e = w.live_e[i];
-    int it = w.it[i], k = w.k[i];
-    const int32_t ss = w.slot_s[i], se = w.slot_e[i];
-    if (ss >= 0) nxt_s = w.vals[ss];
-    if (se >= 0) nxt_e = w.vals[se];
-    if ((ss >= 0 && !isfinite(nxt_s)) || (se >= 0 && !isfinite(nxt_e))) atomicAdd(w.cnt + C_NONFINITE, 1);
-    int32_t *cursor = w.cnt + C_ROUND0 + round;
-    int32_t new_ss = -1, new_se = -1;
-    const bool first = (st == ST_WAIT_FIRST);
-    bool over_s = false, over_e = false;
-    // a ray moves through at most: LS-result -> LS-check -> top-of-loop -> march, i.e. 2 passes
-    for (int pass = 0; pass < 3; ++pass) {
-        if (st == ST_WAIT_FIRST) {
-            // top of the reference's while-loop: threshold, update masks, maybe stop, else march
-            cur_s = live_s ? nxt_s : 0.0f;
-            if (cur_s <= a.thr) cur_s = 0.0f;
-            cur_e = live_e ? nxt_e : 0.0f;
-            if (cur_e <= a.thr) cur_e = 0.0f;
-            live_s = live_s && (cur_s > a.thr);
-            live_e = live_e && (cur_e > a.thr);
-            if (first && pass == 0 && (live_s || live_e)) atomicOr(w.cnt + C_ANY_LIVE, 1);
-            if (!(live_s || live_e) || it == a.max_it) {
-                st = ST_DONE;
-                break;
-            }
-            ++it;
-            t_s = __fadd_rn(t_s, cur_s);
-            t_e = __fsub_rn(t_e, cur_e);
-            nxt_s = 0.0f;
-            nxt_e = 0.0f;
-            if (live_s) new_ss = append_point(a, cursor, i, t_s);
-            if (live_e) new_se = append_point(a, cursor, i, t_e);
-            st = ST_WAIT_MARCH;
-            break;
-        }
-        if (st == ST_WAIT_MARCH) {
-            k = 0;
-        } else {  // ST_WAIT_LS
-            ++k;
-        }
-        over_s = nxt_s < 0.0f;
-        over_e = nxt_e < 0.0f;
-        if (k < a.ls_iters && (over_s || over_e)) {
-            // pull a step that landed inside the surface back by (1 - step)/2^k of the last move
-            const float back = a.back[k];
-            if (over_s) {
-                t_s = __fsub_rn(t_s, __fmul_rn(back, cur_s));
-                new_ss = append_point(a, cursor, i, t_s);
-            }
-            if (over_e) {
-                t_e = __fadd_rn(t_e, __fmul_rn(back, cur_e));
-                new_se = append_point(a, cursor, i, t_e);
-            }
-            st = ST_WAIT_LS;
-            break;
-        }
-        const bool crossed = t_s < t_e;
-        live_s = live_s && crossed;
-        live_e = live_e && crossed;
-        st = ST_WAIT_FIRST;  // fall through to the top of the loop with the values we already hold
-    }
-    w.stage[i] = st;
-    w.t_s[i] = t_s; w.t_e[i] = t_e; w.cur_s[i] = cur_s; w.cur_e[i] = cur_e;
-    w.nxt_s[i] = nxt_s; w.nxt_e[i] = nxt_e;
-    w.live_s[i] = live_s; w.live_e[i] = live_e;
-    w.it[i] = (uint8_t)it; w.k[i] = (uint8_t)k;
-    w.slot_s[i] = new_ss; w.slot_e[i] = new_se;
+    trace_advance_ray(a, i, a.w.cnt + C_ROUND0 + round, 0);
 }
 
 // after the march: network mask, provisional outputs, hand unconverged rays to the sampler
@@ -599,14 +457,23 @@ static int trace_forward_impl(const hm_grid_desc *desc, const hm_nffb_desc *nffb
         return rc;
     };
 
-    // ---- 1. bidirectional sphere tracing: one state-machine round per SDF launch -------------------
-    hipLaunchKernelGGL(trace_init_kernel, dim3(g_rays), dim3(kTB), 0, st, a);
+    // ---- 1. bidirectional sphere tracing ------------------------------------------------------------------
+    // hash-grid networks with the tile size left to the library (or fixed at 16): ONE persistent launch, every
+    // workgroup carries eight rays through all rounds (hm_sdf.hip: trace_march_kernel).  Otherwise one state-machine
+    // round per SDF launch.  HM_TRACE_PERSISTENT=0 forces the launch-per-round form (A/B, tests).
     const int rounds = 1 + cfg->sphere_tracing_iters * (1 + cfg->line_step_iters);
-    for (int r = 0; r < rounds; ++r) {
-        int rc = sdf(2 * n_rays, a.w.cnt + C_ROUND0 + r);
+    static const bool persistent_ok = [] { const char *e = getenv("HM_TRACE_PERSISTENT"); return !(e && atoi(e) == 0); }();
+    if (persistent_ok && !nffb && (tile_points == 0 || tile_points == 16) && a.w.cap >= ((n_rays + 7) / 8) * 16) {
+        const int rc = hm_trace_march_persistent(desc, mlp, table, B_fourier, frac_mode, &a, rounds, stream);
         if (rc != HM_OK) return rc;
-        // round r+1 cursor (the last advance appends nothing that is evaluated; it only closes states)
-        hipLaunchKernelGGL(trace_advance_kernel, dim3(g_rays), dim3(kTB), 0, st, a, r + 1 < 64 ? r + 1 : 63);
+    } else {
+        hipLaunchKernelGGL(trace_init_kernel, dim3(g_rays), dim3(kTB), 0, st, a);
+        for (int r = 0; r < rounds; ++r) {
+            int rc = sdf(2 * n_rays, a.w.cnt + C_ROUND0 + r);
+            if (rc != HM_OK) return rc;
+            // round r+1 cursor (the last advance appends nothing that is evaluated; it only closes states)
+            hipLaunchKernelGGL(trace_advance_kernel, dim3(g_rays), dim3(kTB), 0, st, a, r + 1 < 64 ? r + 1 : 63);
+        }
     }
     hipLaunchKernelGGL(trace_finalize_kernel, dim3(g_rays), dim3(kTB), 0, st, a);
 

@@ -200,21 +200,32 @@ class ImplicitNetwork(nn.Module):
             self._beta_cache = (key, float(self.dencity_net.get_beta().detach()))
         return self._beta_cache[1]
 
-    def _fused(self, x, sdf_only):
+    def _fused(self, x, sdf_only, tile_points=None):
+        tile = self.sdf_tile_points if tile_points is None else tile_points
         emb = self._hash_embedder()
         if emb is None:     # filter-bank embedder: its own fused kernel, then the MLP kernel on the embedding rows
             e = ops.nffb_fwd(self._nffb_embedder(), x)
-            return ops.sdf_fwd_emb(self.packed_weights(), e, sdf_only=sdf_only, tile_points=self.sdf_tile_points)
+            return ops.sdf_fwd_emb(self.packed_weights(), e, sdf_only=sdf_only, tile_points=tile)
         return ops.sdf_fwd(emb.desc, self.packed_weights(), x, emb.table.detach(), emb.freq_encoding.B,
-                           ops.FRAC_MODES[emb.frac_mode], sdf_only=sdf_only, tile_points=self.sdf_tile_points)
+                           ops.FRAC_MODES[emb.frac_mode], sdf_only=sdf_only, tile_points=tile)
 
-    def sdf(self, x):
+    def sdf(self, x, tile_points=None):
         """no-grad SDF values [N] - the callable handed to RayTracing (reference passes
-        ``lambda x: self.implicit_network(x)[:, 0]``, implicit_differentiable_renderer.py:257)."""
+        ``lambda x: self.implicit_network(x)[:, 0]``, implicit_differentiable_renderer.py:257).
+        tile_points: tile size of the fused kernel for this call (default: self.sdf_tile_points)."""
         with torch.no_grad():
             if self._fusable():
-                return self._fused(x, True)
+                return self._fused(x, True, tile_points)
             return self.forward(x)[:, 0]
+
+    def march_tile_points(self):
+        """Tile size of the sphere-tracing march's SDF evaluations: the device tracer's persistent march kernel
+        (csrc/hm_sdf.hip: trace_march_kernel - hash-grid networks, tile size left to the library or fixed at 16) runs
+        every round on the 16-point body; the generic tracer asks for the same, so the two searches see bit-identical
+        values.  None: no special rule (the call's own tile size)."""
+        if self._hash_embedder() is not None and self.sdf_tile_points in (0, 16) and ops.trace_march_persistent():
+            return 16
+        return None
 
     # ---- forward ----------------------------------------------------------------------------
     def forward(self, input, compute_grad=False):

@@ -117,12 +117,14 @@ def test_device_tracer_equals_generic_tracer_2048_rays(golden):
     assert st["sdf_evals"] > 2048 * 20
 
 
-@pytest.mark.parametrize("tile", [0, 64])
+@pytest.mark.parametrize("tile", [0, 16, 64])
 @pytest.mark.parametrize("mode", ["train", "eval"])
 def test_device_tracer_equals_generic_tracer_C2(golden, mode, tile):
     """Benchmarked configuration (L=16, T=2^19 -> E=67), 2048 rays.  tile 0 = the tile size is chosen per call from the
     live point count: on the host by the generic tracer, on the device by the sync-free one - the same rule, so the
-    two searches must still agree bit for bit."""
+    two searches must still agree bit for bit.  tile 0 and 16 run the march as ONE persistent launch
+    (hm_sdf.hip: trace_march_kernel, every round on the 16-point body - the generic tracer asks its network for the same
+    tile size in its march rounds), tile 64 the launch-per-round form."""
     st = _device_vs_host("C2", golden, mode, tile=tile)
     assert st["sdf_evals"] > 2048 * 10 and st.get("nonfinite", 0) == 0
 
