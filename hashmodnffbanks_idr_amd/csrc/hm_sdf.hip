@@ -1093,47 +1093,54 @@ __global__ __launch_bounds__(kThreadsSdf, 1) void sdf_fwd_small_kernel(HmLevels 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Persistent sphere-tracing march (reference: model/ray_tracing.py:98-187): a workgroup owns EIGHT rays - at most 16
-// pending points, the start and the end of each - and carries them through ALL rounds of the state machine: evaluate
-// the pending points with the small-tile body that fits their number (16 / 8 / 4 points), run trace_advance_ray for
-// its own rays, repeat until every one of them is done.  Rays are independent, so nothing is exchanged between
-// workgroups and nothing synchronises the grid: the 41 (SDF launch, update launch) pairs the launch-per-round search
-// enqueues - 30 of them empty whenever no ray needs a line search - become ONE launch, and a workgroup whose rays
-// have converged leaves.  The pending points live in the workgroup's own 16 slots of pts / vals (cursor in LDS).
-// Every round runs on the 16-point body: the march's SDF values are bit-identical to hm_sdf_fwd with tile_points = 16
-// (the rule the generic tracer follows for its march rounds, model/ray_tracing.py).  The 8- / 4-point bodies for
-// workgroups with few live points were tried here: with them inlined beside the 16-point body the kernel needs more than
-// 256 registers and the weight rings spill (58 - 88 spilled VGPRs).
-// (out of line: inlined into the kernel the state machine's registers are live across the three tile bodies, which
-//  sit at the 256-register limit already, and the weight rings spill)
-__device__ __attribute__((noinline)) void march_init_ray(const TraceArgs &a, int64_t ray, int32_t *cursor, int32_t slot_base) {
-    trace_init_ray(a, ray, cursor, slot_base);
+// Persistent TAIL of the sphere-tracing march (reference: model/ray_tracing.py:98-187).  The search needs
+// 1 + sphere_tracing_iters rounds when no ray runs a line search and up to 1 + iters * (1 + line_step_iters) = 41 when
+// one does in every iteration; the launch-per-round form must enqueue all 41 (SDF launch, update launch) pairs, and
+// the 30 surplus pairs - empty launches, ~4.7 us of dispatch each - cost more than a live round.  Rays are independent,
+// so the surplus rounds need no grid at all: after the guaranteed rounds this kernel gives every workgroup EIGHT rays
+// (at most 16 pending points, in 16 slots of its own behind the compact list; cursor in LDS) and lets it carry them
+// through all remaining rounds - evaluate the pending points on the 16-point body, run trace_advance_ray for its own
+// rays, repeat until they are done.  Nothing is exchanged between workgroups, nothing synchronises the grid; a
+// workgroup without stragglers (the usual case: every one) leaves at once.  The guaranteed rounds stay launches of
+// their own: there the compact list balances the live points over all CUs (a march of the whole search inside this
+// kernel was measured: -0.21 ms per step with every ray live to the end, +0.20 ms with a third of them live - the
+// slowest workgroup sets the time).  SDF values: the 16-point body's (bit-identical to hm_sdf_fwd, tile_points = 16).
+// (the per-ray functions are out of line: inlined, their registers are live across the tile body)
+__device__ __attribute__((noinline)) void march_adopt_ray(const TraceArgs &a, int64_t i, int32_t *cursor, int32_t slot_base) {
+    // a ray that is not done has pending points in the compact list of round `first`: move them to this workgroup's slots
+    const TraceWs &w = a.w;
+    if (w.stage[i] == ST_DONE) return;
+    const int32_t ss = w.slot_s[i], se = w.slot_e[i];
+    w.slot_s[i] = ss >= 0 ? append_point(a, cursor, slot_base, i, w.t_s[i]) : -1;
+    w.slot_e[i] = se >= 0 ? append_point(a, cursor, slot_base, i, w.t_e[i]) : -1;
 }
 __device__ __attribute__((noinline)) void march_advance_ray(const TraceArgs &a, int64_t ray, int32_t *cursor, int32_t slot_base) {
     trace_advance_ray(a, ray, cursor, slot_base);
 }
 
 template <int FRAC>
-__global__ __launch_bounds__(kThreadsSdf, 1) void trace_march_kernel(HmLevels lv, SdfNet net,
-                                                                      const float *__restrict__ table,
-                                                                      const float *__restrict__ Bf, TraceArgs a,
-                                                                      int rounds, int lds_floats) {
+__global__ __launch_bounds__(kThreadsSdf, 1) void trace_march_tail_kernel(HmLevels lv, SdfNet net,
+                                                                           const float *__restrict__ table,
+                                                                           const float *__restrict__ Bf, TraceArgs a,
+                                                                           int first, int rounds, int lds_floats) {
     extern __shared__ __align__(16) float lds[];
+    if (a.w.cnt[C_ROUND0 + first] == 0) return;     // no ray has a pending point: every state machine has finished
     int32_t *ctl = reinterpret_cast<int32_t *>(lds + lds_floats);   // [0] cursor of the round being filled
     const int tid = threadIdx.x;
-    const int32_t slot_base = (int32_t)blockIdx.x * 16;
+    const int32_t slot_base = (int32_t)a.w.cap + (int32_t)blockIdx.x * 16;   // (second region of pts / vals)
     const int64_t ray = (int64_t)blockIdx.x * 8 + tid;
     const bool mine = tid < 8 && ray < a.n;
     const float *xp = a.w.pts + (int64_t)slot_base * 3;
     float *vp = a.w.vals + slot_base;
     if (tid == 0) ctl[0] = 0;
     __syncthreads();
-    if (mine) march_init_ray(a, ray, ctl, slot_base);
+    if (mine) march_adopt_ray(a, ray, ctl, slot_base);
     __syncthreads();
-    for (int r = 0; r < rounds; ++r) {
+    for (int r = first; r < rounds; ++r) {
         const int n_loc = ctl[0];
         if (n_loc == 0) break;      // (uniform) every ray of this workgroup is done
-        if (tid == 0) atomicAdd(a.w.cnt + C_ROUND0 + r, n_loc);     // the search's evaluation count (statistics)
+        // the search's evaluation count (statistics; round `first` was counted when its points were appended)
+        if (tid == 0 && r > first) atomicAdd(a.w.cnt + C_ROUND0 + r, n_loc);
         sdf_m16_body<FRAC>(lv, net, xp, n_loc, table, Bf, vp, 1, 1, lds, 0, 1 << 30);
         __syncthreads();            // the values (global stores of this workgroup) are visible to its threads
         if (tid == 0) ctl[0] = 0;
@@ -1215,33 +1222,33 @@ static int sdf_net_from_desc(const HmLevels &lv, const hm_mlp_desc *mlp, int64_t
     return HM_OK;
 }
 
-// internal entry of the ray search (hm_trace.hip, not exported): the whole sphere-tracing march as ONE launch
-// (trace_march_kernel).  `trace_args` = a TraceArgs of hm_trace_dev.h; the caller has zeroed its counters.
-int hm_trace_march_persistent(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *table,
-                              const float *B_fourier, int frac_mode, const void *trace_args, int rounds,
-                              void *stream) {
-    HM_CHECK_ARG(desc && mlp && table && B_fourier && trace_args, "hm_trace_march_persistent: NULL argument");
-    HM_CHECK_ARG(frac_mode == HM_FRAC_REFERENCE || frac_mode == HM_FRAC_TRILINEAR, "hm_trace_march_persistent: bad frac_mode");
+// internal entry of the ray search (hm_trace.hip, not exported): rounds [first, rounds) of the sphere-tracing march as
+// ONE launch (trace_march_tail_kernel).  `trace_args` = a TraceArgs of hm_trace_dev.h.
+int hm_trace_march_tail(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *table, const float *B_fourier,
+                        int frac_mode, const void *trace_args, int first, int rounds, void *stream) {
+    HM_CHECK_ARG(desc && mlp && table && B_fourier && trace_args, "hm_trace_march_tail: NULL argument");
+    HM_CHECK_ARG(frac_mode == HM_FRAC_REFERENCE || frac_mode == HM_FRAC_TRILINEAR, "hm_trace_march_tail: bad frac_mode");
+    HM_CHECK_ARG(first >= 1 && first < 64 && rounds <= 64, "hm_trace_march_tail: bad round range");
     const TraceArgs &a = *static_cast<const TraceArgs *>(trace_args);
     SdfNet net;
     bool have16 = false;
     const int rc = sdf_net_from_desc(desc->lv, mlp, 0, net, have16);
     if (rc != HM_OK) return rc;
-    HM_CHECK_ARG(have16, "hm_trace_march_persistent: needs w_packed_m16 in every layer");
-    if (a.n == 0) return HM_OK;
-    HM_CHECK_ARG(a.w.cap >= ((a.n + 7) / 8) * 16, "hm_trace_march_persistent: point buffer too small");
+    HM_CHECK_ARG(have16, "hm_trace_march_tail: needs w_packed_m16 in every layer");
+    if (a.n == 0 || first >= rounds) return HM_OK;
+    HM_CHECK_ARG(a.w.cap >= ((a.n + 7) / 8) * 16, "hm_trace_march_tail: point buffer too small");
     const int emb_b16 = (desc->lv.E + 15) / 16;
     const int lds_floats = (net.x_groups + emb_b16 * 4) * kGroupFloats16 + kPts16 * 4 + kWaves * kPts16;
     const size_t lds = sizeof(float) * (size_t)lds_floats + 64;
-    HM_CHECK_ARG(lds <= 64 * 1024, "hm_trace_march_persistent: network does not fit the 16-point LDS tile");
+    HM_CHECK_ARG(lds <= 64 * 1024, "hm_trace_march_tail: network does not fit the 16-point LDS tile");
     const unsigned grid = (unsigned)((a.n + 7) / 8);
     if (frac_mode == HM_FRAC_REFERENCE)
-        hipLaunchKernelGGL(trace_march_kernel<HM_FRAC_REFERENCE>, dim3(grid), dim3(kThreadsSdf), lds, as_stream(stream),
-                           desc->lv, net, table, B_fourier, a, rounds, lds_floats);
+        hipLaunchKernelGGL(trace_march_tail_kernel<HM_FRAC_REFERENCE>, dim3(grid), dim3(kThreadsSdf), lds,
+                           as_stream(stream), desc->lv, net, table, B_fourier, a, first, rounds, lds_floats);
     else
-        hipLaunchKernelGGL(trace_march_kernel<HM_FRAC_TRILINEAR>, dim3(grid), dim3(kThreadsSdf), lds, as_stream(stream),
-                           desc->lv, net, table, B_fourier, a, rounds, lds_floats);
-    HM_CHECK_LAUNCH("hm_trace_march_persistent");
+        hipLaunchKernelGGL(trace_march_tail_kernel<HM_FRAC_TRILINEAR>, dim3(grid), dim3(kThreadsSdf), lds,
+                           as_stream(stream), desc->lv, net, table, B_fourier, a, first, rounds, lds_floats);
+    HM_CHECK_LAUNCH("hm_trace_march_tail");
     return HM_OK;
 }
 

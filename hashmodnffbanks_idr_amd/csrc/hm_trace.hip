@@ -17,10 +17,10 @@
 
 #include <stdlib.h>
 
-// hm_sdf.hip (not exported): the whole sphere-tracing march as one persistent launch
-extern "C" int hm_trace_march_persistent(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *table,
-                                         const float *B_fourier, int frac_mode, const void *trace_args, int rounds,
-                                         void *stream);
+// hm_sdf.hip (not exported): rounds [first, rounds) of the sphere-tracing march as one persistent launch
+extern "C" int hm_trace_march_tail(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *table,
+                                   const float *B_fourier, int frac_mode, const void *trace_args, int first, int rounds,
+                                   void *stream);
 
 namespace {
 
@@ -457,23 +457,27 @@ static int trace_forward_impl(const hm_grid_desc *desc, const hm_nffb_desc *nffb
         return rc;
     };
 
-    // ---- 1. bidirectional sphere tracing ------------------------------------------------------------------
-    // hash-grid networks with the tile size left to the library (or fixed at 16): ONE persistent launch, every
-    // workgroup carries eight rays through all rounds (hm_sdf.hip: trace_march_kernel).  Otherwise one state-machine
-    // round per SDF launch.  HM_TRACE_PERSISTENT=0 forces the launch-per-round form (A/B, tests).
+    // ---- 1. bidirectional sphere tracing: one state-machine round per SDF launch -------------------
+    // 1 + sphere_tracing_iters rounds are needed when no ray runs a line search, `rounds` when one does in every
+    // iteration.  Hash-grid networks with the tile size left to the library (or fixed at 16) run the surplus rounds as
+    // ONE persistent launch in which every workgroup carries eight rays to the end (hm_sdf.hip: trace_march_tail_kernel;
+    // it returns at once when no ray is left) instead of 30 (empty SDF launch, empty update launch) pairs.
+    // HM_TRACE_PERSISTENT=0: every round a launch pair (A/B).
     const int rounds = 1 + cfg->sphere_tracing_iters * (1 + cfg->line_step_iters);
     static const bool persistent_ok = [] { const char *e = getenv("HM_TRACE_PERSISTENT"); return !(e && atoi(e) == 0); }();
-    if (persistent_ok && !nffb && (tile_points == 0 || tile_points == 16) && a.w.cap >= ((n_rays + 7) / 8) * 16) {
-        const int rc = hm_trace_march_persistent(desc, mlp, table, B_fourier, frac_mode, &a, rounds, stream);
+    const bool tail = persistent_ok && !nffb && (tile_points == 0 || tile_points == 16) &&
+                      a.w.cap >= ((n_rays + 7) / 8) * 16 && cfg->line_step_iters > 0;
+    const int launched = tail ? 1 + cfg->sphere_tracing_iters : rounds;
+    hipLaunchKernelGGL(trace_init_kernel, dim3(g_rays), dim3(kTB), 0, st, a);
+    for (int r = 0; r < launched; ++r) {
+        int rc = sdf(2 * n_rays, a.w.cnt + C_ROUND0 + r);
         if (rc != HM_OK) return rc;
-    } else {
-        hipLaunchKernelGGL(trace_init_kernel, dim3(g_rays), dim3(kTB), 0, st, a);
-        for (int r = 0; r < rounds; ++r) {
-            int rc = sdf(2 * n_rays, a.w.cnt + C_ROUND0 + r);
-            if (rc != HM_OK) return rc;
-            // round r+1 cursor (the last advance appends nothing that is evaluated; it only closes states)
-            hipLaunchKernelGGL(trace_advance_kernel, dim3(g_rays), dim3(kTB), 0, st, a, r + 1 < 64 ? r + 1 : 63);
-        }
+        // round r+1 cursor (the last advance appends nothing that is evaluated; it only closes states)
+        hipLaunchKernelGGL(trace_advance_kernel, dim3(g_rays), dim3(kTB), 0, st, a, r + 1 < 64 ? r + 1 : 63);
+    }
+    if (tail) {
+        const int rc = hm_trace_march_tail(desc, mlp, table, B_fourier, frac_mode, &a, launched, rounds, stream);
+        if (rc != HM_OK) return rc;
     }
     hipLaunchKernelGGL(trace_finalize_kernel, dim3(g_rays), dim3(kTB), 0, st, a);
 

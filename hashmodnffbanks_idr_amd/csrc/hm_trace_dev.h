@@ -69,8 +69,8 @@ __device__ __forceinline__ void along(const TraceArgs &a, int64_t i, float t, fl
 }
 
 // `cursor` counts the points of the round; the point's slot in pts / vals is slot_base + its ticket.  The launch-per-round
-// search uses a global cursor (slot_base 0: one compact list for the whole batch); the persistent march kernel
-// (hm_sdf.hip) gives every workgroup a cursor in LDS and 16 slots of its own.
+// search uses a global cursor (slot_base 0: one compact list for the whole batch); the persistent tail of the march
+// (hm_sdf.hip: trace_march_tail_kernel) gives every workgroup a cursor in LDS and 16 slots of its own.
 __device__ __forceinline__ int32_t append_point(const TraceArgs &a, int32_t *cursor, int32_t slot_base, int64_t i,
                                                 float t) {
     const int32_t idx = slot_base + atomicAdd(cursor, 1);

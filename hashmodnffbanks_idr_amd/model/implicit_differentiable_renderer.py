@@ -218,15 +218,6 @@ class ImplicitNetwork(nn.Module):
                 return self._fused(x, True, tile_points)
             return self.forward(x)[:, 0]
 
-    def march_tile_points(self):
-        """Tile size of the sphere-tracing march's SDF evaluations: the device tracer's persistent march kernel
-        (csrc/hm_sdf.hip: trace_march_kernel - hash-grid networks, tile size left to the library or fixed at 16) runs
-        every round on the 16-point body; the generic tracer asks for the same, so the two searches see bit-identical
-        values.  None: no special rule (the call's own tile size)."""
-        if self._hash_embedder() is not None and self.sdf_tile_points in (0, 16) and ops.trace_march_persistent():
-            return 16
-        return None
-
     # ---- forward ----------------------------------------------------------------------------
     def forward(self, input, compute_grad=False):
         needs_graph = torch.is_grad_enabled() and (input.requires_grad or any(p.requires_grad for p in self.parameters()))

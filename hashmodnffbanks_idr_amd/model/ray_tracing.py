@@ -116,16 +116,7 @@ class RayTracing(nn.Module):
         t_sphere = t_sphere.reshape(N, 2)
         hit = hit.reshape(N)
 
-        # the package's own network evaluates the march rounds with the tile size the device tracer's march uses
-        # (ImplicitNetwork.march_tile_points), so that the two searches stay bit-identical
-        sdf_march = sdf
-        own = getattr(sdf, "__self__", None)
-        if own is not None and hasattr(own, "march_tile_points") and \
-                getattr(sdf, "__func__", None) is getattr(type(own), "sdf", None) and own._fusable():
-            mt = own.march_tile_points()
-            if mt is not None:
-                sdf_march = lambda x: own.sdf(x, tile_points=mt)     # noqa: E731
-        pts, unfinished, t_start, t_end, t_min, t_max = self._sphere_trace(sdf_march, cams, dirs, hit, t_sphere)
+        pts, unfinished, t_start, t_end, t_min, t_max = self._sphere_trace(sdf, cams, dirs, hit, t_sphere)
         net_mask = t_start < t_end
 
         sampler_mask = unfinished

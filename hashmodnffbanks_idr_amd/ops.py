@@ -773,13 +773,6 @@ def trace_workspace_bytes(n_rays, cfg, nffb_levels=0):
     return check(lib().hm_trace_workspace_bytes(int(n_rays), C.byref(cfg)))
 
 
-def trace_march_persistent():
-    """hm_trace_forward runs the sphere-tracing march as one persistent launch (HM_TRACE_PERSISTENT=0: one launch per
-    round; read by the library when it is first used)"""
-    import os
-    return os.environ.get("HM_TRACE_PERSISTENT", "1") != "0"
-
-
 def trace_forward(desc, packed, table, B, frac_mode, tile_points, cfg, cam_loc, ray_dirs, object_mask, t_sphere,
                   hit_mask, rays_per_image, sampler_fracs, steps_u, workspace, stats=None, nffb=None):
     """Enqueues the whole intersection search (no host sync).  Returns (points, net_mask_u8, dists).

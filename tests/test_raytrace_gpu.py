@@ -100,6 +100,21 @@ def _device_vs_host(tag, golden, mode, n_rays=None, seed=0, tile=64):
             st = rt.last_stats
             assert st["unfinished"] == 0
     (p1, m1, d1), (p2, m2, d2) = outs
+    if tile == 0:
+        # tile size left to the library: the device tracer's persistent march picks the small-tile body from each
+        # WORKGROUP's pending points (8 rays), the generic tracer's SDF calls pick it from the whole batch's - the bodies
+        # (4 / 8 / 16 points: different MFMA shapes) agree to ~1e-7, not to the bit, so a ray at a threshold may take
+        # another branch.  Bit-for-bit equality is asserted with fixed tile sizes (16: the persistent kernel, 64).
+        flips = int((m1 != m2).sum())
+        both = m1 & m2
+        dd = (d1 - d2).abs()
+        close = dd <= 1e-4 * (1.0 + d2.abs())
+        frac_far = 1.0 - float(close.float().mean())
+        print(f"tile 0: {flips} mask flips of {m1.numel()} rays, max |d dist| on common hits "
+              f"{float(dd[both].max()) if bool(both.any()) else 0.0:.3e}, rays beyond 1e-4: {frac_far:.4f}")
+        assert flips <= max(1, m1.numel() // 200)
+        assert frac_far <= 0.01
+        return st
     assert torch.equal(m1, m2)
     assert torch.equal(d1, d2), (d1 - d2).abs().max()
     assert torch.equal(p1, p2), (p1 - p2).abs().max()
@@ -108,12 +123,13 @@ def _device_vs_host(tag, golden, mode, n_rays=None, seed=0, tile=64):
 
 @pytest.mark.parametrize("tag", ["init", "bumpy"])
 @pytest.mark.parametrize("mode", ["train", "eval"])
-def test_device_tracer_equals_generic_tracer(golden, tag, mode):
-    _device_vs_host(tag, golden, mode)
+@pytest.mark.parametrize("tile", [16, 64])
+def test_device_tracer_equals_generic_tracer(golden, tag, mode, tile):
+    _device_vs_host(tag, golden, mode, tile=tile)
 
 
 def test_device_tracer_equals_generic_tracer_2048_rays(golden):
-    st = _device_vs_host("bumpy", golden, "train", n_rays=2048, seed=11)
+    st = _device_vs_host("bumpy", golden, "train", n_rays=2048, seed=11, tile=16)
     assert st["sdf_evals"] > 2048 * 20
 
 
@@ -121,17 +137,17 @@ def test_device_tracer_equals_generic_tracer_2048_rays(golden):
 @pytest.mark.parametrize("mode", ["train", "eval"])
 def test_device_tracer_equals_generic_tracer_C2(golden, mode, tile):
     """Benchmarked configuration (L=16, T=2^19 -> E=67), 2048 rays.  tile 0 = the tile size is chosen per call from the
-    live point count: on the host by the generic tracer, on the device by the sync-free one - the same rule, so the
-    two searches must still agree bit for bit.  tile 0 and 16 run the march as ONE persistent launch
-    (hm_sdf.hip: trace_march_kernel, every round on the 16-point body - the generic tracer asks its network for the same
-    tile size in its march rounds), tile 64 the launch-per-round form."""
+    live point count (see _device_vs_host: near-equality).  tile 16 runs the march as ONE persistent launch with every
+    round on the 16-point body (hm_sdf.hip: trace_march_kernel), tile 64 the launch-per-round form: both must agree
+    with the generic tracer bit for bit."""
     st = _device_vs_host("C2", golden, mode, tile=tile)
     assert st["sdf_evals"] > 2048 * 10 and st.get("nonfinite", 0) == 0
 
 
+@pytest.mark.parametrize("tile", [16, 64])
 @pytest.mark.parametrize("case", ["one_ray", "all_miss_sphere", "mask_all_false", "mask_all_true", "odd_count"])
 @pytest.mark.parametrize("mode", ["train", "eval"])
-def test_device_tracer_edge_cases(golden, case, mode):
+def test_device_tracer_edge_cases(golden, case, mode, tile):
     """Degenerate batches the reference's masked code paths handle implicitly (ray_tracing.py:46-95: empty
     selections, rays that miss the bounding sphere, no / all rays inside the object mask): device tracer ==
     generic tracer, bit for bit."""
@@ -140,7 +156,7 @@ def test_device_tracer_edge_cases(golden, case, mode):
     g = golden("raytrace_bumpy")
     net = make_implicit("C1", (512,) * 8, 256, int(g["seed"]), float(g["perturb"]), float(g["table_scale"]))
     net.eval()
-    net.sdf_tile_points = 64
+    net.sdf_tile_points = tile      # 16: persistent march kernel (77 rays: a last workgroup with 5 rays), 64: a launch per round
     n = {"one_ray": 1, "odd_count": 77}.get(case, 64)
     cam, dirs = P.make_rays(5, n)
     om = np.random.RandomState(5).uniform(0, 1, n) < 0.6
