@@ -291,13 +291,13 @@ __device__ __forceinline__ void pipe_fetch(const float *const (&p)[PER], int64_t
         }
     }
 }
-template <int OCT>
+template <int OCT, int AROWS = 64>
 __device__ __forceinline__ void pipe_read_ops(const float *as, const float *bs, int arow, int brow, int h,
                                               float4 (&xa)[OCT], float4 (&xb)[OCT]) {
 #pragma unroll
     for (int oo = 0; oo < OCT; ++oo) {
         const int kg = 2 * oo + h;
-        xa[oo] = *reinterpret_cast<const float4 *>(as + lds_slot<64>(kg, arow));
+        xa[oo] = *reinterpret_cast<const float4 *>(as + lds_slot<AROWS>(kg, arow));
         xb[oo] = *reinterpret_cast<const float4 *>(bs + lds_slot<64>(kg, brow));
     }
 }
@@ -387,14 +387,19 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(GemmArgs g) {
 
 // Same pipeline with EIGHT waves: two wave groups split the octets of every stage (two waves per SIMD hide each
 // other's barrier / LDS turnarounds), partial tiles are summed through LDS at the end.
-template <bool AKC, bool BKC, bool EP>
+// WM = 3: a 96 x 64 tile on TWELVE waves (two groups of 3 x 2), for row counts whose 64-row grid is between one and two
+// rounds of the chip: M = 3072, N = 512 are 384 tiles of 64 x 64 - a CU with two of them takes twice as long as the one
+// with one - but exactly 256 of 96 x 64.  The B panel is staged by the first 512 threads.
+template <bool AKC, bool BKC, bool EP, int WM = 2>
 __device__ __forceinline__ void gemm_pipe2_body(const GemmArgs &g, int bx, int by, int bz) {
-    constexpr int BM = 64, BN = 64, BK = kPipeBK, NT = 512, PER = BM * BK / 4 / NT, KG = BK / 4, OCT = BK / 8 / 2;   // OCT: octets of a stage per wave group
+    constexpr int BM = 32 * WM, BN = 64, BK = kPipeBK, NT = 256 * WM, NTB = 512, PER = BM * BK / 4 / NT, KG = BK / 4,
+                  OCT = BK / 8 / 2;   // OCT: octets of a stage per wave group
+    static_assert(PER == 1 && BN * BK / 4 / NTB == 1, "one k-group per thread and operand");
     __shared__ __align__(16) float As[2][BK * BM];
     __shared__ __align__(16) float Bs[2][BK * BN];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
-    const int kpart = wave >> 2, wsub = wave & 3;   // two wave groups split the octets of every stage
+    const int kpart = wave / (2 * WM), wsub = wave % (2 * WM);   // two wave groups split the octets of every stage
     const int wm = wsub >> 1, wn = wsub & 1;
     const int j = lane & 31, h = lane >> 5;
     const int m0 = bx * BM, n0 = by * BN;
@@ -405,13 +410,15 @@ __device__ __forceinline__ void gemm_pipe2_body(const GemmArgs &g, int bx, int b
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int e = tid + NT * i;
+        const int eb = (tid % NTB) + NTB * i;   // (WM = 3: threads 512.. fetch a B k-group again and do not stage it)
         // rows / columns past the edge of a partial tile are clamped HERE, once (they compute values nobody stores)
-        const int am = min(m0 + (AKC ? e / KG : e % BM), g.M - 1), bn = min(n0 + (BKC ? e / KG : e % BN), g.N - 1);
+        const int am = min(m0 + (AKC ? e / KG : e % BM), g.M - 1), bn = min(n0 + (BKC ? eb / KG : eb % BN), g.N - 1);
         pa[i] = AKC ? g.A + (int64_t)am * g.lda + kbeg + (e % KG) * 4
                     : g.A + (int64_t)(kbeg + (e / BM) * 4) * g.lda + am;
-        pb[i] = BKC ? g.B + (int64_t)bn * g.ldb + kbeg + (e % KG) * 4
-                    : g.B + (int64_t)(kbeg + (e / BN) * 4) * g.ldb + bn;
+        pb[i] = BKC ? g.B + (int64_t)bn * g.ldb + kbeg + (eb % KG) * 4
+                    : g.B + (int64_t)(kbeg + (eb / BN) * 4) * g.ldb + bn;
     }
+    const bool stage_b = NT == NTB || tid < NTB;
     const int64_t sa = AKC ? BK : (int64_t)BK * g.lda, sb = BKC ? BK : (int64_t)BK * g.ldb;
     const int64_t lda = g.lda, ldb = g.ldb;
     f32x16 acc, acc2;   // even / odd k-octets: two independent MFMA chains for the one wave on each SIMD
@@ -432,9 +439,9 @@ __device__ __forceinline__ void gemm_pipe2_body(const GemmArgs &g, int bx, int b
     HM_PIPE_FETCH(1, ra1, rb1);
     HM_PIPE_FETCH(2, ra2, rb2);
     store_tile<BM, BK, NT>(As[0], AKC, tid, ra0);
-    store_tile<BN, BK, NT>(Bs[0], BKC, tid, rb0);
+    if (stage_b) store_tile<BN, BK, NTB>(Bs[0], BKC, tid, rb0);
     __syncthreads();
-    pipe_read_ops<OCT>(As[0], Bs[0], wm * 32 + j, wn * 32 + j, h + 4 * kpart, opa0, opb0);
+    pipe_read_ops<OCT, BM>(As[0], Bs[0], wm * 32 + j, wn * 32 + j, h + 4 * kpart, opa0, opb0);
 // one stage: multiply from operand set C, meanwhile fetch stage s+D-1 into ring slot F and move ring slot N (stage
 // s+1) through LDS buffer NB into operand set X
 #define HM_PIPE_STAGE(S_, F_, N_, C_, X_, NB_)                                                      \
@@ -442,9 +449,9 @@ __device__ __forceinline__ void gemm_pipe2_body(const GemmArgs &g, int bx, int b
         HM_PIPE_FETCH((S_) + kPipeD - 1, ra##F_, rb##F_);                                                    \
         pipe_mfma_oct(opa##C_[0], opb##C_[0], acc);                                                 \
         store_tile<BM, BK, NT>(As[NB_], AKC, tid, ra##N_);                                          \
-        store_tile<BN, BK, NT>(Bs[NB_], BKC, tid, rb##N_);                                          \
+        if (stage_b) store_tile<BN, BK, NTB>(Bs[NB_], BKC, tid, rb##N_);                            \
         __syncthreads();                                                                            \
-        pipe_read_ops<OCT>(As[NB_], Bs[NB_], wm * 32 + j, wn * 32 + j, h + 4 * kpart, opa##X_, opb##X_);        \
+        pipe_read_ops<OCT, BM>(As[NB_], Bs[NB_], wm * 32 + j, wn * 32 + j, h + 4 * kpart, opa##X_, opb##X_);        \
         pipe_mfma_oct(opa##C_[1], opb##C_[1], acc2);                                                \
     } while (0)
     static_assert(OCT == 2, "HM_PIPE_STAGE is written for 2 octets per stage and wave group");
@@ -460,8 +467,8 @@ __device__ __forceinline__ void gemm_pipe2_body(const GemmArgs &g, int bx, int b
     for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
     {   // add the second wave group's partial tile (through the staging buffers, free now)
         __syncthreads();
-        float *red = &As[0][0];   // 4 waves * 16 registers * 64 lanes floats == 2 * BK * BM
-        static_assert(2 * BK * BM >= 4 * 16 * 64, "reduction buffer");
+        float *red = &As[0][0];   // 2 WM waves * 16 registers * 64 lanes floats == 2 * BK * BM
+        static_assert(2 * BK * BM >= 2 * WM * 16 * 64, "reduction buffer");
         if (kpart == 1) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) red[(wsub * 16 + r) * 64 + lane] = acc[r];
@@ -478,6 +485,10 @@ __device__ __forceinline__ void gemm_pipe2_body(const GemmArgs &g, int bx, int b
 template <bool AKC, bool BKC, bool EP>
 __global__ __launch_bounds__(512, 4) void gemm_f32_pipe2_kernel(GemmArgs g) {
     gemm_pipe2_body<AKC, BKC, EP>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+template <bool AKC, bool BKC, bool EP>
+__global__ __launch_bounds__(768, 3) void gemm_f32_pipe2_m96_kernel(GemmArgs g) {
+    gemm_pipe2_body<AKC, BKC, EP, 3>(g, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Grouped form for the weight gradients of one backward pass: C_p += A_p^T B_p for up to HM_GEMM_GROUP_MAX problems in ONE
@@ -576,12 +587,17 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K, co
     const int64_t t64 = ((M + 63) / 64) * ((N + 63) / 64);
     static const int half_cfg = [] { const char *e = getenv("HM_GEMM_HALF"); return e ? atoi(e) : 0; }();
     const bool half_rows = !big && small_cfg == 0 && half_cfg != 0 && t64 >= 128 && t64 < 512 && M >= 256;
-    const int64_t bm = big ? 128 : (half_rows ? 32 : 64), bn = big ? 128 : 64;
     static const int pipe_cfg = [] { const char *e = getenv("HM_GEMM_PIPE"); return e ? atoi(e) : 2; }();   // 2 = eight-wave variant
     // the pipelined kernel takes K ranges that are a whole number of 128-deep groups per split and operands that are
     // either k-contiguous + 16-B aligned or row-contiguous (partial edge tiles are fine: clamped rows, guarded stores)
     const bool use_pipe = !big && small_cfg == 0 && !half_rows && pipe_cfg != 0 &&
                           K % (kPipeBK * kPipeD) == 0 && K > 0 && (!a_kc || g.vecA) && (!b_kc || g.vecB);
+    // 96-row tiles when they need fewer rounds of the chip per row of the tile (M = 3072, N = 512: 384 tiles of 64 rows -
+    // the slowest CU runs two = 128 rows' worth - against 256 tiles of 96).  HM_GEMM_M96=0: always 64-row tiles (A/B).
+    static const int m96_cfg = [] { const char *e = getenv("HM_GEMM_M96"); return e ? atoi(e) : 1; }();
+    const int64_t t96 = ((M + 95) / 96) * ((N + 63) / 64);
+    const bool m96 = use_pipe && pipe_cfg == 2 && m96_cfg != 0 && ((t96 + 255) / 256) * 96 < ((t64 + 255) / 256) * 64;
+    const int64_t bm = big ? 128 : (half_rows ? 32 : (m96 ? 96 : 64)), bn = big ? 128 : 64;
     const int64_t kBK = big ? 32 : (use_pipe ? kPipeBK * kPipeD : (small_cfg == 1 || small_cfg == 2 ? 64 : 128));
     const int64_t tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
     int64_t split = 1;
@@ -640,7 +656,12 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K, co
     else if (pipe_ok) {
 #define HM_PIPE_LAUNCH(AKC_, BKC_)                                                                                \
     do {                                                                                                          \
-        if (pipe_cfg == 2) {                                                                                      \
+        if (m96) {                                                                                                \
+            if (g.ep.mode != HM_EPI_NONE)                                                                         \
+                hipLaunchKernelGGL((gemm_f32_pipe2_m96_kernel<AKC_, BKC_, true>), grid, dim3(768), 0, st, g);     \
+            else                                                                                                  \
+                hipLaunchKernelGGL((gemm_f32_pipe2_m96_kernel<AKC_, BKC_, false>), grid, dim3(768), 0, st, g);    \
+        } else if (pipe_cfg == 2) {                                                                               \
             if (g.ep.mode != HM_EPI_NONE)                                                                         \
                 hipLaunchKernelGGL((gemm_f32_pipe2_kernel<AKC_, BKC_, true>), grid, dim3(512), 0, st, g);         \
             else                                                                                                  \

@@ -22,7 +22,9 @@ def _close(got, ref, what):
     np.testing.assert_allclose(got.double().cpu().numpy(), ref.cpu().numpy(), rtol=2e-5, atol=atol, err_msg=what)
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 445, 67), (2100, 512, 512), (64, 257, 512), (1, 5, 3)])
+# (3072 / 2700 rows: the 96 x 64 tile of the pipelined kernel - whole and with a ragged last row tile, 445 = ragged columns)
+@pytest.mark.parametrize("M,N,K", [(300, 445, 67), (2100, 512, 512), (64, 257, 512), (1, 5, 3), (3072, 512, 512),
+                                   (2700, 445, 512)])
 def test_gemm_epilogues(M, N, K):
     from hashmodnffbanks_idr_amd import ops
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
