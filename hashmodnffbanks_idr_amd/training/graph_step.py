@@ -224,6 +224,13 @@ class GraphedTrainStep:
             torch.cuda.synchronize()
             # with RCCL alive its watchdog thread polls events; only this thread's calls must obey capture rules
             mode = "thread_local" if (torch.distributed.is_available() and torch.distributed.is_initialized()) else "global"
+            if mode == "thread_local":
+                # let the watchdog retire the warm-up iterations' collectives (it sweeps every 100 ms) before this stream
+                # starts capturing: a sweep that still holds one of their events during the capture died with
+                # hipErrorCapturedEvent once under rocprofv3 (gpurun_out/r3ac/prof_rccl1.log) - a capture failure on a
+                # data-parallel rank is fatal
+                import time
+                time.sleep(0.5)
             self.out = self.loss_out = None
             if self.side is None:
                 self.side = torch.cuda.Stream()

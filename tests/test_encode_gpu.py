@@ -89,7 +89,8 @@ def test_encode_bwd_table_golden(golden, cfg):
     gt = emb.table.grad.cpu().numpy()
     nz = np.nonzero(np.abs(gt).sum(1))[0]
     assert np.array_equal(nz, g["nz_rows"])
-    np.testing.assert_allclose(gt[nz], g["nz_grad"], rtol=1e-5, atol=1e-6)
+    # (fp32 atomics in arrival order: rows of the tiny table sum ~100 terms of magnitude 1; 1.07e-6 seen on one element)
+    np.testing.assert_allclose(gt[nz], g["nz_grad"], rtol=1e-5, atol=4e-6)
 
 
 def test_encode_double_backward_linear_in_table():
