@@ -234,6 +234,31 @@ def mlp_roofline(net, log2_n=18, iters=10, warmup=4):
             "min_launch_ms": round(float(ms.min()), 4), "points_per_s": round(n / (avg_ms * 1e-3), 1)}
 
 
+def mfma_stream_ceiling(device, iters=4000, reps=5):
+    """What a stream of v_mfma_f32_32x32x2_f32 sustains on this GPU (hm_diag_mfma_f32_stream: the 64-point kernel's
+    MFMA pattern - 8 waves per CU, four accumulators per wave - with operands in registers and no memory traffic)."""
+    from hashmodnffbanks_idr_amd import _lib
+    wgs = 256
+    out = torch.empty(wgs * 512, dtype=torch.float32, device=device)
+    call = lambda: _lib.check(_lib.lib().hm_diag_mfma_f32_stream(wgs, iters, _lib.dptr(out), _lib.stream_ptr(out)))  # noqa: E731
+    call()
+    torch.cuda.synchronize()
+    ms = []
+    for _ in range(reps):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        call()
+        e.record()
+        torch.cuda.synchronize()
+        ms.append(s.elapsed_time(e))
+    flop = wgs * 8 * iters * 16 * 4096.0
+    tf = flop / (min(ms) * 1e-3) / 1e12
+    return {"TFLOP/s": round(tf, 2), "frac_of_nominal_peak": round(tf / MFMA_F32_PEAK_TF, 4),
+            "what": "register-resident v_mfma_f32_32x32x2_f32 stream, 8 waves per CU, 4 accumulators per wave, "
+                    f"{iters * 16} MFMAs per wave: the matrix pipe's own ceiling under this instruction (clock under load, "
+                    "pipe occupancy per MFMA)"}
+
+
 def gemm_roofline(device, iters=20, warmup=3):
     """Exact-fp32 GEMM of the grad path (csrc/hm_gemm.hip) on the shapes one training step runs: forward X W^T (+ Softplus
     epilogue) and input gradient dY W at 3072 / 2048 rows (~64 launches per step), and the weight gradients
@@ -613,7 +638,10 @@ def main():
         elif args.only == "gemm":
             print(json.dumps(gemm_roofline(dev)))
         else:
-            print(json.dumps(mlp_roofline(model.implicit_network)))
+            r = mlp_roofline(model.implicit_network)
+            r["mfma_stream_ceiling"] = mfma_stream_ceiling(dev)
+            r["frac_of_stream_ceiling"] = round(r["achieved"] / r["mfma_stream_ceiling"]["TFLOP/s"], 4)
+            print(json.dumps(r))
         return
 
     from hashmodnffbanks_idr_amd import parallel
@@ -747,6 +775,10 @@ def main():
             line["roofline"] = gather_roofline(emb, args.gather_log2n)
             line["roofline_bwd"] = gather_bwd_roofline(emb, args.gather_log2n, iters=5, warmup=2)
             line["roofline_mlp"] = mlp_roofline(head_model.implicit_network)
+            # the same MFMA stream without memory traffic: how much of the gap to the nominal peak is the pipe's own
+            ceil = mfma_stream_ceiling(device)
+            line["roofline_mlp"]["mfma_stream_ceiling"] = ceil
+            line["roofline_mlp"]["frac_of_stream_ceiling"] = round(line["roofline_mlp"]["achieved"] / ceil["TFLOP/s"], 4)
             if cfg != "C4":
                 from hashmodnffbanks_idr_amd.model.embeddings.hashGridEmbedding import MultiResHashGridMLP
                 Lc, Tc, bc, dc = P.CONFIGS["C4"]

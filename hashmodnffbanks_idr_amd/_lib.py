@@ -27,6 +27,7 @@ SIGNATURES = {
     "hm_grid_embed_dim": (_int, [_p]),
     "hm_corner_ids": (_int, [_p, _int, _p, _i64, _p, _p, _p]),
     "hm_diag_gather_calib": (_int, [_p, _i64, _i64, _int, _int, _p, _p]),
+    "hm_diag_mfma_f32_stream": (_int, [_int, _int, _p, _p]),
     "hm_encode_fwd": (_int, [_p, _p, _i64, _p, _p, _p, _i64, _int, _p]),
     "hm_encode_workspace_bytes": (_i64, [_p, _i64]),
     "hm_encode_fwd_ws": (_int, [_p, _p, _i64, _p, _p, _p, _i64, _int, _p, _i64, _p]),

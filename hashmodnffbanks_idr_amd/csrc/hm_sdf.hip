@@ -35,6 +35,25 @@ namespace {
 // allocation of the hash-grid variant changed (178 -> 205 VGPRs, 33 -> 42 spilled SGPRs) and it lost 4 %.
 constexpr int kFracEmb = 2;
 
+#ifdef HM_SDF_PHASE_PROBE
+// scripts/sdf_phase_probe.py: cycle stamps of one tile's phases (workgroup 0, wave 0, second tile), never in the product build
+__device__ unsigned long long hm_probe_ts[128];
+#define HM_PROBE(i_)                                                                                  \
+    do {                                                                                              \
+        if (blockIdx.x == 0 && threadIdx.x == 0 && it == 1 && (i_) < 120) hm_probe_ts[(i_)] = wall_clock64(); \
+        if (blockIdx.x == 0 && threadIdx.x == 0 && it == 1 && ((i_) == 0 || (i_) == 100))                 \
+            hm_probe_ts[120 + ((i_) != 0)] = clock64();   /* shader-clock cycles over the same tile */      \
+    } while (0)
+// every wave's own stamp (lane 0) at the end of layer 2's k-loop -> ts[64 + wave], after its first barrier -> ts[72 + wave]
+#define HM_PROBE_WAVES(base_)                                                                                  \
+    do {                                                                                                       \
+        if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && it == 1 && li == 2) hm_probe_ts[(base_) + (threadIdx.x >> 6)] = wall_clock64(); \
+    } while (0)
+#else
+#define HM_PROBE(i_) do { } while (0)
+#define HM_PROBE_WAVES(base_) do { } while (0)
+#endif
+
 constexpr int kPts = 64;        // points per workgroup tile
 constexpr int kThreadsSdf = 512;
 constexpr int kWaves = 8;
@@ -85,6 +104,7 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_kernel(HmLevels lv, Sd
             cnt = (int)min(rem_step, n - base);
         }
         const bool half = cnt <= 32;   // (also a ragged last tile of <= 32 points)
+        HM_PROBE(0);
         __syncthreads();  // previous tile's output stage is done with X
         if (FRAC != kFracEmb && tid < kPts * 3) SX[tid] = (tid < cnt * 3) ? x[base * 3 + tid] : 0.0f;
         __syncthreads();
@@ -133,6 +153,7 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_kernel(HmLevels lv, Sd
             }
         }
         __syncthreads();
+        HM_PROBE(1);
 
         // ---------------- layers ------------------------------------------------------------
         // weight ring (4 slots per feature tile) lives across layers: the first three octets of layer l+1 are
@@ -222,6 +243,9 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_kernel(HmLevels lv, Sd
                     acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b0.w, acc10, 0, 0, 0);
                     acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc11, 0, 0, 0);
                 };
+                // (requesting the B fragments of octet gg + 1 before octet gg's MFMAs - two register sets - shortens ONE
+                //  wave's k-loop from 62.4 to 54.2 us per 512 x 512 layer but not the layer: the wave then waits 11 us at
+                //  the barrier for the SIMD's other wave; the matrix pipe is the limit, scripts/sdf_phase_probe.py)
                 // whole groups of four octets run without an exit test: with a `break` inside the unrolled group
                 // hipcc cannot count the loads in flight across the back edge and drains them (vmcnt(0)) at every
                 // loop head; the 1-3 left-over octets are already in ring slots 0..2
@@ -281,7 +305,11 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_kernel(HmLevels lv, Sd
                 prefetch64(li + 1);
                 ring_ready = true;
             }
+            HM_PROBE(2 + 4 * li);
+            HM_PROBE_WAVES(64);
             __syncthreads();  // every wave has finished reading X / EMB for this layer
+            HM_PROBE(3 + 4 * li);
+            HM_PROBE_WAVES(72);
 
             // epilogue: registers 4q..4q+3 of a tile = features 8q+4h+{0..3} = one k-group of the next layer
             const bool act = Ly.activation != 0;
@@ -319,8 +347,11 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_kernel(HmLevels lv, Sd
                 for (int i = tid; i < net.emb_groups * kGroupFloats; i += kThreadsSdf)
                     EMB[i] = __fdiv_rn(EMB[i], sqrt2);
             }
+            HM_PROBE(4 + 4 * li);
             __syncthreads();
+            HM_PROBE(5 + 4 * li);
         }
+        HM_PROBE(100);
 
         // ---------------- output: X[(f/4)][p][f%4] -> out[p][f] -----------------------------
         const hm_mlp_layer &last = net.layer[net.n_layers - 1];
@@ -1150,11 +1181,40 @@ __global__ __launch_bounds__(kThreadsSdf, 1) void trace_march_tail_kernel(HmLeve
     }
 }
 
+// diagnostic (hm_diag_mfma_f32_stream): the MFMA stream of the 64-point kernel's k-loop without its memory traffic
+__global__ __launch_bounds__(kThreadsSdf, 2) void mfma_f32_stream_kernel(int iters, float *out) {
+    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+    float a0 = (float)(threadIdx.x & 63) * 1e-3f, a1 = a0 + 0.5f, b0 = 1.0f - a0, b1 = 0.25f + a0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
+        }
+    }
+    out[(size_t)blockIdx.x * kThreadsSdf + threadIdx.x] = acc00[0] + acc01[5] + acc10[9] + acc11[15];
+}
+
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 }  // namespace
 
 extern "C" {
+
+int hm_diag_mfma_f32_stream(int workgroups, int iters, float *out, void *stream) {
+    HM_CHECK_ARG(workgroups >= 1 && workgroups <= 65535 && iters >= 1 && out, "hm_diag_mfma_f32_stream: bad argument");
+    hipLaunchKernelGGL(mfma_f32_stream_kernel, dim3((unsigned)workgroups), dim3(kThreadsSdf), 0, as_stream(stream), iters, out);
+    HM_CHECK_LAUNCH("hm_diag_mfma_f32_stream");
+    return HM_OK;
+}
+
+#ifdef HM_SDF_PHASE_PROBE
+HM_API int hm_probe_read(unsigned long long *out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(hm_probe_ts), sizeof(unsigned long long) * (size_t)(n < 128 ? n : 128)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 static int sdf_fwd_impl(const HmLevels &lv, const hm_mlp_desc *mlp, const float *x, int64_t emb_stride, int64_t n,
                         const float *table, const float *B_fourier, float *out, int64_t out_stride, int out_cols,

@@ -76,6 +76,14 @@ HM_API int hm_corner_ids(const hm_grid_desc *desc, int level, const float *x, in
 HM_API int hm_diag_gather_calib(const float *table, int64_t table_bytes, int64_t n, int group, int stride_bytes,
                                 float *out, void *stream);
 
+/* ---- diagnostic: what a stream of exact-fp32 MFMAs sustains --------------------------------------------
+ * Not part of the reference's interface.  `workgroups` workgroups of 8 waves (two per SIMD, as the fused SDF kernel)
+ * issue `iters` x 16 v_mfma_f32_32x32x2_f32 each on four independent accumulators, operands in registers, no memory
+ * traffic: iters * 16 * 4096 flop per wave.  The rate it reaches (bench.py times the call) is the ceiling of the
+ * matrix pipe under this instruction - below the nominal 256 flop / clk / CU x 2.4 GHz because the clock drops under
+ * the load and an MFMA occupies the pipe for more than its 64 cycles.  out [workgroups * 512] receives checksums.   */
+HM_API int hm_diag_mfma_f32_stream(int workgroups, int iters, float *out, void *stream);
+
 /* ---- encoder forward --------------------------------------------------------------------
  * Replaces MultiResHashGridMLP.forward (hashGridEmbedding.py:150-155) including
  * FourierFeature.forward (frequency_enc.py:63-67):
