@@ -467,7 +467,12 @@ static int trace_forward_impl(const hm_grid_desc *desc, const hm_nffb_desc *nffb
     static const bool persistent_ok = [] { const char *e = getenv("HM_TRACE_PERSISTENT"); return !(e && atoi(e) == 0); }();
     const bool tail = persistent_ok && !nffb && (tile_points == 0 || tile_points == 16) &&
                       a.w.cap >= ((n_rays + 7) / 8) * 16 && cfg->line_step_iters > 0;
-    const int launched = tail ? 1 + cfg->sphere_tracing_iters : rounds;
+    int launched = tail ? 1 + cfg->sphere_tracing_iters : rounds;
+    if (tail) {   // HM_TRACE_TAIL_FIRST=k (tests): hand over to the persistent kernel after k rounds already (read per call)
+        const char *e = getenv("HM_TRACE_TAIL_FIRST");
+        const int k = e ? atoi(e) : 0;
+        if (k >= 1 && k < launched) launched = k;
+    }
     hipLaunchKernelGGL(trace_init_kernel, dim3(g_rays), dim3(kTB), 0, st, a);
     for (int r = 0; r < launched; ++r) {
         int rc = sdf(2 * n_rays, a.w.cnt + C_ROUND0 + r);

@@ -229,3 +229,46 @@ def test_static_step_reusing_the_ray_rows_equals_re_evaluating_them():
         worst = max(worst, (g0[n] - g1[n]).abs().max().item() / scale)
     print(f"reuse of the ray rows: worst gradient difference / tensor scale {worst:.3e}")
     assert worst <= 2e-5
+
+
+def test_local_table_grad_equals_autograd_accumulation(monkeypatch):
+    """training/graph_step.LocalTableGrad (every table backward of the static step scatters into ONE dense gradient bound
+    as table.grad) against autograd's per-node dense gradients + adds (HM_LOCAL_TABLE_GRAD=0): the same gradients after
+    replayed steps (weights held: lr = 0, so both runs see the same iteration), up to the arrival order of the fp32
+    atomics."""
+    import bench
+    from helpers import idr_conf
+    from hashmodnffbanks_idr_amd.model.implicit_differentiable_renderer import IDRNetwork
+    from hashmodnffbanks_idr_amd.model.loss import IDRLoss
+    from hashmodnffbanks_idr_amd.training.graph_step import GraphedTrainStep
+    from hashmodnffbanks_idr_amd.training.optim import ClipAdam
+    res = []
+    for local in ("1", "0"):
+        monkeypatch.setenv("HM_LOCAL_TABLE_GRAD", local)
+        torch.manual_seed(0)
+        model = IDRNetwork(idr_conf("C1")).cuda()
+        with torch.no_grad():     # (the geometric initialisation zeroes the weights of the hash-feature columns)
+            model.implicit_network.lin0.weight_v[:, 3:].normal_(0, 0.02)
+            model.implicit_network.embed_model.embedder_obj.table.uniform_(-0.05, 0.05)
+        model.train()
+        opt = ClipAdam(model.parameters(), lr=0.0, max_norm=1.0)
+        stepper = GraphedTrainStep(model, IDRLoss(eikonal_weight=0.1, mask_weight=100.0, alpha=50.0), opt, None, warmup=2)
+        assert bool(stepper.local_tables) == (local == "1")
+        inp, gt = bench.synthetic_batch(7, 512, "cuda")
+        torch.manual_seed(5)
+        for _ in range(5):
+            stepper.step(inp, gt)
+        torch.cuda.synchronize()
+        assert stepper.g_fb is not None
+        res.append({n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+    assert set(res[0]) == set(res[1])
+    worst = 0.0
+    for n in res[0]:
+        d = (res[0][n] - res[1][n]).abs().max().item()
+        worst = max(worst, d / (res[1][n].abs().max().item() + 1e-30))
+        if n.endswith("table"):
+            rows = [int((r[n].abs().sum(1) > 0).sum()) for r in res]
+            print(f"{n}: rows with a gradient {rows}")
+            assert rows[0] == rows[1] and (rows[0] > 100 or not n.startswith("implicit_network"))   # (not two empty tensors)
+    print(f"LocalTableGrad vs autograd accumulation, replayed step: worst gradient difference / tensor scale {worst:.3e}")
+    assert worst <= 2e-5

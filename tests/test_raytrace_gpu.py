@@ -144,6 +144,19 @@ def test_device_tracer_equals_generic_tracer_C2(golden, mode, tile):
     assert st["sdf_evals"] > 2048 * 10 and st.get("nonfinite", 0) == 0
 
 
+@pytest.mark.parametrize("tag,n_rays", [("bumpy", None), ("bumpy", 2048), ("C2", None)])
+def test_persistent_march_tail_carries_whole_marches(golden, tag, n_rays, monkeypatch):
+    """hm_sdf.hip: trace_march_tail_kernel normally takes over after the 1 + sphere_tracing_iters guaranteed rounds and
+    finds work only when a ray ran line searches.  HM_TRACE_TAIL_FIRST=1 hands over after the FIRST round: every ray's
+    whole march (all iterations, line searches included) then runs inside the persistent kernel, eight rays per
+    workgroup - and must still reproduce the generic tracer bit for bit (16-point tiles on both sides)."""
+    monkeypatch.setenv("HM_TRACE_TAIL_FIRST", "1")
+    st = _device_vs_host(tag, golden, "train", n_rays=n_rays, seed=3, tile=16)
+    assert st["sdf_evals"] > 0 and st.get("nonfinite", 0) == 0
+    monkeypatch.setenv("HM_TRACE_TAIL_FIRST", "4")
+    _device_vs_host(tag, golden, "eval", n_rays=n_rays, seed=4, tile=16)
+
+
 @pytest.mark.parametrize("tile", [16, 64])
 @pytest.mark.parametrize("case", ["one_ray", "all_miss_sphere", "mask_all_false", "mask_all_true", "odd_count"])
 @pytest.mark.parametrize("mode", ["train", "eval"])
