@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_kernel(HmLevels lv, Sd
     float *RED = SX + kPts * 4;                                // [8][64] cross-wave partial sums
 
     const int tid = threadIdx.x;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: the weight pointers below stay in SGPRs)
     const int lane = tid & 63;
     const int j = lane & 31;  // point within a 32-point tile / feature row within a 32-feature tile
     const int h = lane >> 5;
@@ -161,17 +161,26 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_kernel(HmLevels lv, Sd
         // restart from an empty pipe behind the two barriers of every layer
         float4 r0[4], r1[4];
         bool ring_ready = false;
+        const int lane16 = lane * 16;
+        auto ldw = [&](const __amdgpu_buffer_rsrc_t &rs, int soff) -> float4 {
+            const auto u = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, soff, 0);
+            return make_float4(__uint_as_float(u[0]), __uint_as_float(u[1]), __uint_as_float(u[2]), __uint_as_float(u[3]));
+        };
         auto prefetch64 = [&](int l) {
             const hm_mlp_layer &Lp = net.layer[l];
             const int nop = Lp.seg_octets[0] + Lp.seg_octets[1];
             const int ntp = max(0, min(2, Lp.n_tiles - 2 * wave));
-            const float4 *P0 = reinterpret_cast<const float4 *>(Lp.w_packed) + ((size_t)(2 * wave) * nop) * 64 + lane;
-            const float4 *P1 = P0 + (ntp > 1 ? (size_t)nop * 64 : 0);
+            // buffer loads: descriptor (SGPRs) on the wave's first feature tile, lane * 16 as the one loop-invariant VGPR
+            // offset, the octet / tile offset as the scalar offset - no per-load 64-bit address arithmetic on the VALU,
+            // whose instructions are serial with the MFMAs of both waves on the SIMD
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float *>(Lp.w_packed) + ((size_t)(2 * wave) * nop) * 256, 0, 0x7fffffff, 0x00020000);
+            const int t1 = ntp > 1 ? nop * 1024 : 0;
 #pragma unroll
             for (int st = 0; st < 3; ++st) {
-                const size_t off = (size_t)min(st, nop - 1) * 64;
-                r0[st] = P0[off];
-                r1[st] = P1[off];
+                const int off = min(st, nop - 1) * 1024;
+                r0[st] = ldw(rs, off);
+                r1[st] = ldw(rs, t1 + off);
             }
         };
         for (int li = 0; li < net.n_layers; ++li) {
@@ -214,8 +223,9 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_kernel(HmLevels lv, Sd
             if (ntw > 0) {
                 // weight stream: 4-deep register ring (3 octets = 6 KB per wave in flight), unconditional
                 // clamped loads so that hipcc emits counted vmcnt waits instead of draining per octet
-                const float4 *A0 = reinterpret_cast<const float4 *>(Ly.w_packed) + ((size_t)t0 * n_oct) * 64 + lane;
-                const float4 *A1 = A0 + (ntw > 1 ? (size_t)n_oct * 64 : 0);
+                const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float *>(Ly.w_packed) + ((size_t)t0 * n_oct) * 256, 0, 0x7fffffff, 0x00020000);
+                const int tA1 = ntw > 1 ? n_oct * 1024 : 0;     // byte offset of the wave's second feature tile
                 const int no0 = Ly.seg_octets[0];
                 const float *src0 = (Ly.seg_src[0] == 0) ? X : EMB;
                 const float *src1 = (Ly.seg_src[1] == 0) ? X : EMB;
@@ -270,9 +280,9 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_kernel(HmLevels lv, Sd
                         for (int u = 0; u < 4; ++u) {
                             const int gg = gg0 + u;
                             {
-                                const size_t off = (size_t)min(gg + 3, n_oct - 1) * 64;
-                                r0[(u + 3) & 3] = A0[off];
-                                r1[(u + 3) & 3] = A1[off];
+                                const int off = min(gg + 3, n_oct - 1) * 1024;
+                                r0[(u + 3) & 3] = ldw(rsA, off);
+                                r1[(u + 3) & 3] = ldw(rsA, tA1 + off);
                             }
                             __builtin_amdgcn_sched_barrier(0);   // (loads stay ahead of this octet's MFMAs; see the 16-point body)
                             octet(gg, r0[u], r1[u]);
@@ -287,9 +297,9 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_kernel(HmLevels lv, Sd
                         for (int u = 0; u < 4; ++u) {
                             const int gg = gg0 + u;
                             {
-                                const size_t off = (size_t)min(gg + 3, n_oct - 1) * 64;
-                                r0[(u + 3) & 3] = A0[off];
-                                r1[(u + 3) & 3] = A1[off];
+                                const int off = min(gg + 3, n_oct - 1) * 1024;
+                                r0[(u + 3) & 3] = ldw(rsA, off);
+                                r1[(u + 3) & 3] = ldw(rsA, tA1 + off);
                             }
                             __builtin_amdgcn_sched_barrier(0);
                             octet_h(gg, r0[u], r1[u]);
