@@ -54,6 +54,17 @@ __device__ unsigned long long hm_probe_ts[128];
 #define HM_PROBE_WAVES(base_) do { } while (0)
 #endif
 
+// 16 bytes of a packed weight image: buffer load with the descriptor in SGPRs, `voff` = lane * 16 (one loop-invariant
+// VGPR) and the tile / octet offset as the SCALAR offset - no per-load 64-bit address arithmetic on the VALU, whose
+// instructions are serial with the MFMAs of both waves on a SIMD (r3af: 128 -> 132 TFLOP/s on the 64-point kernel)
+__device__ __forceinline__ float4 ld_w16(const __amdgpu_buffer_rsrc_t &rs, int voff, int soff) {
+    const auto u = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    return make_float4(__uint_as_float(u[0]), __uint_as_float(u[1]), __uint_as_float(u[2]), __uint_as_float(u[3]));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t w_rsrc(const float *base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, 0x7fffffff, 0x00020000);
+}
+
 constexpr int kPts = 64;        // points per workgroup tile
 constexpr int kThreadsSdf = 512;
 constexpr int kWaves = 8;
@@ -162,10 +173,7 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_kernel(HmLevels lv, Sd
         float4 r0[4], r1[4];
         bool ring_ready = false;
         const int lane16 = lane * 16;
-        auto ldw = [&](const __amdgpu_buffer_rsrc_t &rs, int soff) -> float4 {
-            const auto u = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, soff, 0);
-            return make_float4(__uint_as_float(u[0]), __uint_as_float(u[1]), __uint_as_float(u[2]), __uint_as_float(u[3]));
-        };
+        auto ldw = [&](const __amdgpu_buffer_rsrc_t &rs, int soff) -> float4 { return ld_w16(rs, lane16, soff); };
         auto prefetch64 = [&](int l) {
             const hm_mlp_layer &Lp = net.layer[l];
             const int nop = Lp.seg_octets[0] + Lp.seg_octets[1];
@@ -632,8 +640,9 @@ __device__ __forceinline__ void sdf_m16_body(const HmLevels &lv, const SdfNet &n
     float *RED = SX + kPts16 * 4;                              // [8][16]
 
     const int tid = threadIdx.x;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: descriptors / scalar offsets of the weight stream)
     const int lane = tid & 63;
+    const int lane16 = lane * 16;
     const int j = lane & 15;  // point
     const int q = lane >> 4;  // k quarter / feature quarter
     const int L = lv.L, F = lv.F, E = lv.E;
@@ -697,13 +706,14 @@ __device__ __forceinline__ void sdf_m16_body(const HmLevels &lv, const SdfNet &n
             const hm_mlp_layer &Lp = net.layer[l];
             const int nbp = Lp.seg_blocks16[0] + Lp.seg_blocks16[1];
             const int ntp = max(0, min(4, Lp.n_tiles * 2 - 4 * wave));
-            const float4 *Ap = reinterpret_cast<const float4 *>(Lp.w_packed_m16) + ((size_t)(4 * wave) * nbp) * 64 + lane;
-            const size_t ts = (size_t)nbp * 64;
-            const size_t p1 = (1 < ntp ? 1 : 0) * ts, p2 = (2 < ntp ? 2 : 0) * ts, p3 = (3 < ntp ? 3 : 0) * ts;
+            const __amdgpu_buffer_rsrc_t rp = w_rsrc(Lp.w_packed_m16 + ((size_t)(4 * wave) * nbp) * 256);
+            const int ts = nbp * 1024;     // bytes to the next feature tile
+            const int p1 = (1 < ntp ? 1 : 0) * ts, p2 = (2 < ntp ? 2 : 0) * ts, p3 = (3 < ntp ? 3 : 0) * ts;
 #pragma unroll
             for (int st = 0; st < kRing16 - 1; ++st) {
-                const size_t off = (size_t)min(st, nbp - 1) * 64;
-                ring[st][0] = Ap[off]; ring[st][1] = Ap[p1 + off]; ring[st][2] = Ap[p2 + off]; ring[st][3] = Ap[p3 + off];
+                const int off = min(st, nbp - 1) * 1024;
+                ring[st][0] = ld_w16(rp, lane16, off); ring[st][1] = ld_w16(rp, lane16, p1 + off);
+                ring[st][2] = ld_w16(rp, lane16, p2 + off); ring[st][3] = ld_w16(rp, lane16, p3 + off);
             }
         };
         for (int li = 0; li < net.n_layers; ++li) {
@@ -751,10 +761,10 @@ __device__ __forceinline__ void sdf_m16_body(const HmLevels &lv, const SdfNet &n
                 // The first kRing16-1 blocks of a layer were requested before the previous layer's epilogue
                 // (`prefetch16` below), so the pipeline does not drain at layer boundaries.
                 // All loads are unconditional (clamped index) so hipcc emits counted vmcnt waits.
-                const float4 *A = reinterpret_cast<const float4 *>(Ly.w_packed_m16) + ((size_t)u0 * nb) * 64 + lane;
-                const size_t tstride = (size_t)nb * 64;  // next feature tile
-                const size_t o1 = (1 < ntw ? 1 : 0) * tstride, o2 = (2 < ntw ? 2 : 0) * tstride,
-                             o3 = (3 < ntw ? 3 : 0) * tstride;
+                const __amdgpu_buffer_rsrc_t rA = w_rsrc(Ly.w_packed_m16 + ((size_t)u0 * nb) * 256);
+                const int tstride = nb * 1024;  // bytes to the next feature tile
+                const int o1 = (1 < ntw ? 1 : 0) * tstride, o2 = (2 < ntw ? 2 : 0) * tstride,
+                          o3 = (3 < ntw ? 3 : 0) * tstride;
                 const int nb0 = Ly.seg_blocks16[0];
                 const float *src0 = (Ly.seg_src[0] == 0) ? X : EMB;
                 const float *src1 = (Ly.seg_src[1] == 0) ? X : EMB;
@@ -783,11 +793,11 @@ __device__ __forceinline__ void sdf_m16_body(const HmLevels &lv, const SdfNet &n
                     for (int u = 0; u < kRing16; ++u) {
                         const int t = tt + u;
                         {
-                            const size_t off = (size_t)min(t + kRing16 - 1, nb - 1) * 64;
-                            ring[(u + kRing16 - 1) % kRing16][0] = A[off];
-                            ring[(u + kRing16 - 1) % kRing16][1] = A[o1 + off];
-                            ring[(u + kRing16 - 1) % kRing16][2] = A[o2 + off];
-                            ring[(u + kRing16 - 1) % kRing16][3] = A[o3 + off];
+                            const int off = min(t + kRing16 - 1, nb - 1) * 1024;
+                            ring[(u + kRing16 - 1) % kRing16][0] = ld_w16(rA, lane16, off);
+                            ring[(u + kRing16 - 1) % kRing16][1] = ld_w16(rA, lane16, o1 + off);
+                            ring[(u + kRing16 - 1) % kRing16][2] = ld_w16(rA, lane16, o2 + off);
+                            ring[(u + kRing16 - 1) % kRing16][3] = ld_w16(rA, lane16, o3 + off);
                         }
                         // keep the four loads HERE: left to itself hipcc sinks them below this block's MFMAs (their
                         // destination registers double as MFMA temporaries), which halves the bytes in flight
@@ -875,8 +885,9 @@ __device__ __forceinline__ void sdf_m8_body(const HmLevels &lv, const SdfNet &ne
     float *RED = SX + kPts8 * 4;                              // [8 waves][8 points]
 
     const int tid = threadIdx.x;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: descriptors / scalar offsets of the weight stream)
     const int lane = tid & 63;
+    const int lane16 = lane * 16;
     const int q = lane >> 4;         // k quarter of the A operand
     const int jj = (lane & 15) >> 2; // feature quad within the 16-feature tile
     const int p4 = lane & 3;         // point within a group of four
@@ -943,13 +954,14 @@ __device__ __forceinline__ void sdf_m8_body(const HmLevels &lv, const SdfNet &ne
             const hm_mlp_layer &Lp = net.layer[l];
             const int nbp = Lp.seg_blocks16[0] + Lp.seg_blocks16[1];
             const int ntp = max(0, min(4, Lp.n_tiles * 2 - 4 * wave));
-            const float4 *Ap = reinterpret_cast<const float4 *>(Lp.w_packed_m16) + ((size_t)(4 * wave) * nbp) * 64 + lane;
-            const size_t ts = (size_t)nbp * 64;
-            const size_t p1 = (1 < ntp ? 1 : 0) * ts, p2 = (2 < ntp ? 2 : 0) * ts, p3 = (3 < ntp ? 3 : 0) * ts;
+            const __amdgpu_buffer_rsrc_t rp = w_rsrc(Lp.w_packed_m16 + ((size_t)(4 * wave) * nbp) * 256);
+            const int ts = nbp * 1024;     // bytes to the next feature tile
+            const int p1 = (1 < ntp ? 1 : 0) * ts, p2 = (2 < ntp ? 2 : 0) * ts, p3 = (3 < ntp ? 3 : 0) * ts;
 #pragma unroll
             for (int st = 0; st < RD8 - 1; ++st) {
-                const size_t off = (size_t)min(st, nbp - 1) * 64;
-                ring[st][0] = Ap[off]; ring[st][1] = Ap[p1 + off]; ring[st][2] = Ap[p2 + off]; ring[st][3] = Ap[p3 + off];
+                const int off = min(st, nbp - 1) * 1024;
+                ring[st][0] = ld_w16(rp, lane16, off); ring[st][1] = ld_w16(rp, lane16, p1 + off);
+                ring[st][2] = ld_w16(rp, lane16, p2 + off); ring[st][3] = ld_w16(rp, lane16, p3 + off);
             }
         };
         for (int li = 0; li < net.n_layers; ++li) {
@@ -996,10 +1008,10 @@ __device__ __forceinline__ void sdf_m8_body(const HmLevels &lv, const SdfNet &ne
                 acc1[a] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             }
             if (ntw > 0) {
-                const float4 *A = reinterpret_cast<const float4 *>(Ly.w_packed_m16) + ((size_t)u0 * nb) * 64 + lane;
-                const size_t tstride = (size_t)nb * 64;
-                const size_t o1 = (1 < ntw ? 1 : 0) * tstride, o2 = (2 < ntw ? 2 : 0) * tstride,
-                             o3 = (3 < ntw ? 3 : 0) * tstride;
+                const __amdgpu_buffer_rsrc_t rA = w_rsrc(Ly.w_packed_m16 + ((size_t)u0 * nb) * 256);
+                const int tstride = nb * 1024;
+                const int o1 = (1 < ntw ? 1 : 0) * tstride, o2 = (2 < ntw ? 2 : 0) * tstride,
+                          o3 = (3 < ntw ? 3 : 0) * tstride;
                 const int nb0 = Ly.seg_blocks16[0];
                 const float *src0 = (Ly.seg_src[0] == 0) ? X : EMB;
                 const float *src1 = (Ly.seg_src[1] == 0) ? X : EMB;
@@ -1029,11 +1041,11 @@ __device__ __forceinline__ void sdf_m8_body(const HmLevels &lv, const SdfNet &ne
                     for (int u = 0; u < RD8; ++u) {
                         const int t = tt + u;
                         {
-                            const size_t off = (size_t)min(t + RD8 - 1, nb - 1) * 64;
-                            ring[(u + RD8 - 1) % RD8][0] = A[off];
-                            ring[(u + RD8 - 1) % RD8][1] = A[o1 + off];
-                            ring[(u + RD8 - 1) % RD8][2] = A[o2 + off];
-                            ring[(u + RD8 - 1) % RD8][3] = A[o3 + off];
+                            const int off = min(t + RD8 - 1, nb - 1) * 1024;
+                            ring[(u + RD8 - 1) % RD8][0] = ld_w16(rA, lane16, off);
+                            ring[(u + RD8 - 1) % RD8][1] = ld_w16(rA, lane16, o1 + off);
+                            ring[(u + RD8 - 1) % RD8][2] = ld_w16(rA, lane16, o2 + off);
+                            ring[(u + RD8 - 1) % RD8][3] = ld_w16(rA, lane16, o3 + off);
                         }
                         __builtin_amdgcn_sched_barrier(0);   // loads stay ahead of this block's MFMAs
                         block8(t, ring[u]);
