@@ -160,7 +160,12 @@ def test_idr_training_steps(golden, merge, cfg, n_steps):
                 if soft.any() and bad[soft].any():
                     print(f"    [relaxed bound] {name}: {int(bad[soft].sum())} / {int(soft.sum())} eps-regime entries off "
                           f"({int(bad[firm].sum())} / {int(firm.sum())} firm entries off)")
-                    assert bad[soft].mean() <= (0.35 if mism == 0 else 0.5), (name, bad[soft].sum(), soft.sum())
+                    # (a count bound with some room for tensors that have only a handful of such entries - lin8.bias at
+                    #  C4 has 9, of which 2 - 4 move with the arrival order of the weight-gradient atomics, r3ah - and,
+                    #  below, every entry within one update of the reference)
+                    assert bad[soft].sum() <= max((0.35 if mism == 0 else 0.5) * soft.sum(), 5), \
+                        (name, bad[soft].sum(), soft.sum())
+                    assert np.abs(got - ref)[soft].max() <= 1.1e-4, name
                 assert np.abs(got - ref).max() <= 2.5e-4, name
             print(f"    parameters after one Adam step: worst fraction of sampled entries off by a sign flip {worst:.3f}")
 
