@@ -57,7 +57,7 @@ __global__ __launch_bounds__(kTB16, 2) void sdf_fwd_bf16_kernel(HmLevels lv, Sdf
     float *RED = SX + kPB * 4;                                                    // [5][kPB] last-layer partial sums
 
     const int tid = threadIdx.x;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: descriptors / scalar offsets of the weight stream)
     const int lane = tid & 63;
     const int j = lane & 31;
     const int h = lane >> 5;
@@ -188,15 +188,17 @@ __global__ __launch_bounds__(kTB16, 2) void sdf_fwd_bf16_kernel(HmLevels lv, Sdf
                     } else {
                         // ---- hidden segment: bf16 (v_mfma_f32_32x32x16_bf16), 1-KB weight blocks through a 4-slot ring
                         const int nbs = Ly.seg_blocks16[seg];
-                        const float4 *A0 = reinterpret_cast<const float4 *>(Ly.w_packed_bf16) +
-                                           ((size_t)t0 * nb + blk0) * 64 + lane;
-                        const float4 *A1 = A0 + (ntw > 1 ? (size_t)nb * 64 : 0);
+                        // (buffer loads: descriptor on the wave's first feature tile, lane * 16 the one VGPR offset, block /
+                        //  tile offsets scalar - no address VALU between the MFMAs, hm_sdf_common.h: ld_w16)
+                        const __amdgpu_buffer_rsrc_t rA =
+                            w_rsrc(reinterpret_cast<const float *>(Ly.w_packed_bf16) + ((size_t)t0 * nb + blk0) * 256);
+                        const int a1 = ntw > 1 ? nb * 1024 : 0, lane16 = lane * 16;
                         Frag16 r0[4], r1[4];
 #pragma unroll
                         for (int st = 0; st < 3; ++st) {
-                            const size_t off = (size_t)min(st, nbs - 1) * 64;
-                            r0[st].f = A0[off];
-                            r1[st].f = A1[off];
+                            const int off = min(st, nbs - 1) * 1024;
+                            r0[st].f = ld_w16(rA, lane16, off);
+                            r1[st].f = ld_w16(rA, lane16, a1 + off);
                         }
                         auto block = [&](int t, const Frag16 &a0, const Frag16 &a1) {
                             const __bf16 *src = X + (size_t)(2 * t + h) * kXOct;
@@ -213,9 +215,9 @@ __global__ __launch_bounds__(kTB16, 2) void sdf_fwd_bf16_kernel(HmLevels lv, Sdf
                             for (int u = 0; u < 4; ++u) {
                                 const int t = tt + u;
                                 {
-                                    const size_t off = (size_t)min(t + 3, nbs - 1) * 64;
-                                    r0[(u + 3) & 3].f = A0[off];
-                                    r1[(u + 3) & 3].f = A1[off];
+                                    const int off = min(t + 3, nbs - 1) * 1024;
+                                    r0[(u + 3) & 3].f = ld_w16(rA, lane16, off);
+                                    r1[(u + 3) & 3].f = ld_w16(rA, lane16, a1 + off);
                                 }
                                 __builtin_amdgcn_sched_barrier(0);
                                 block(t, r0[u], r1[u]);

@@ -14,6 +14,17 @@ struct SdfNet {  // by value -> kernarg
     hm_mlp_layer layer[HM_MAX_LAYERS];
 };
 
+// 16 bytes of a packed weight image: buffer load with the descriptor in SGPRs, `voff` = lane * 16 (one loop-invariant
+// VGPR) and the tile / octet offset as the SCALAR offset - no per-load 64-bit address arithmetic on the VALU, whose
+// instructions are serial with the MFMAs of both waves on a SIMD (r3af: 128 -> 132 TFLOP/s on the 64-point kernel)
+__device__ __forceinline__ float4 ld_w16(const __amdgpu_buffer_rsrc_t &rs, int voff, int soff) {
+    const auto u = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    return make_float4(__uint_as_float(u[0]), __uint_as_float(u[1]), __uint_as_float(u[2]), __uint_as_float(u[3]));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t w_rsrc(const float *base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, 0x7fffffff, 0x00020000);
+}
+
 // tile of precomputed embedding rows -> EMB[(e/4)][p][e%4] (group stride gf floats), zero padded to 4*egroups columns
 __device__ __forceinline__ void load_emb_tile(float *EMB, const float *__restrict__ emb, int64_t stride, int64_t base,
                                               int cnt, int E, int egroups, int pts, int gf, int tid, int nthreads) {

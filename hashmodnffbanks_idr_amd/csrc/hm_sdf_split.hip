@@ -103,7 +103,7 @@ __global__ __launch_bounds__(kTS, 2) void sdf_fwd_split_kernel(HmLevels lv, SdfN
     float *RED = SX + kPS * 4;                                            // [8][kPS] last-layer partial sums
 
     const int tid = threadIdx.x;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: descriptors / scalar offsets of the weight stream)
     const int lane = tid & 63;
     const int j = lane & 31;
     const int h = lane >> 5;
@@ -182,12 +182,15 @@ __global__ __launch_bounds__(kTS, 2) void sdf_fwd_split_kernel(HmLevels lv, SdfN
         constexpr int D = 4;
         FragS<KIND> r0h[D], r0l[D], r1h[D], r1l[D];
         bool ring_ready = false;
-        auto ring_fill = [&](const float4 *A0, const float4 *A1, int nbs) {
+        // (weight stream as buffer loads: descriptor on the wave's first feature tile, lane * 16 the one VGPR offset, block /
+        //  tile offsets scalar - no address arithmetic on the VALU between the MFMAs, hm_sdf_common.h: ld_w16)
+        const int lane16 = lane * 16;
+        auto ring_fill = [&](const __amdgpu_buffer_rsrc_t &rs, int a1, int nbs) {
 #pragma unroll
             for (int st = 0; st < D - 1; ++st) {
-                const size_t off = (size_t)min(st, nbs - 1) * 128;
-                r0h[st].f = A0[off]; r0l[st].f = A0[off + 64];
-                r1h[st].f = A1[off]; r1l[st].f = A1[off + 64];
+                const int off = min(st, nbs - 1) * 2048;
+                r0h[st].f = ld_w16(rs, lane16, off); r0l[st].f = ld_w16(rs, lane16, off + 1024);
+                r1h[st].f = ld_w16(rs, lane16, a1 + off); r1l[st].f = ld_w16(rs, lane16, a1 + off + 1024);
             }
         };
         auto prefetch_layer = [&](int l) {      // segment 0 of layer l, this wave's feature tiles
@@ -195,9 +198,9 @@ __global__ __launch_bounds__(kTS, 2) void sdf_fwd_split_kernel(HmLevels lv, SdfN
             const int ntp = max(0, min(2, Lp.n_tiles - 2 * wave));
             if (ntp <= 0) return false;
             const int nbp = Lp.seg_blocks16[0] + Lp.seg_blocks16[1];
-            const float4 *P0 = reinterpret_cast<const float4 *>(Lp.w_packed_split) + ((size_t)(2 * wave) * nbp) * 128 + lane;
-            const float4 *P1 = P0 + (ntp > 1 ? (size_t)nbp * 128 : 0);
-            ring_fill(P0, P1, Lp.seg_blocks16[0]);
+            const __amdgpu_buffer_rsrc_t rp =
+                w_rsrc(reinterpret_cast<const float *>(Lp.w_packed_split) + ((size_t)(2 * wave) * nbp) * 512);
+            ring_fill(rp, ntp > 1 ? nbp * 2048 : 0, Lp.seg_blocks16[0]);
             return true;
         };
         for (int li = 0; li < net.n_layers; ++li) {
@@ -244,10 +247,10 @@ __global__ __launch_bounds__(kTS, 2) void sdf_fwd_split_kernel(HmLevels lv, SdfN
                     const T *srcH = Ly.seg_src[seg] == 1 ? EH : XH;
                     const T *srcL = Ly.seg_src[seg] == 1 ? EL : XL;
                     // image: [tile][block][hi | lo][lane] float4
-                    const float4 *A0 = reinterpret_cast<const float4 *>(Ly.w_packed_split) +
-                                       ((size_t)t0 * nb + blk0) * 128 + lane;
-                    const float4 *A1 = A0 + (ntw > 1 ? (size_t)nb * 128 : 0);
-                    if (!(seg == 0 && ring_ready)) ring_fill(A0, A1, nbs);
+                    const __amdgpu_buffer_rsrc_t rA =
+                        w_rsrc(reinterpret_cast<const float *>(Ly.w_packed_split) + ((size_t)t0 * nb + blk0) * 512);
+                    const int a1 = ntw > 1 ? nb * 2048 : 0;
+                    if (!(seg == 0 && ring_ready)) ring_fill(rA, a1, nbs);
                     ring_ready = false;
                     auto block = [&](int t, const FragS<KIND> &a0h, const FragS<KIND> &a0l, const FragS<KIND> &a1h,
                                      const FragS<KIND> &a1l) {
@@ -276,9 +279,11 @@ __global__ __launch_bounds__(kTS, 2) void sdf_fwd_split_kernel(HmLevels lv, SdfN
                         for (int u = 0; u < D; ++u) {
                             const int t = tt + u;
                             {
-                                const size_t off = (size_t)min(t + D - 1, nbs - 1) * 128;
-                                r0h[(u + D - 1) % D].f = A0[off]; r0l[(u + D - 1) % D].f = A0[off + 64];
-                                r1h[(u + D - 1) % D].f = A1[off]; r1l[(u + D - 1) % D].f = A1[off + 64];
+                                const int off = min(t + D - 1, nbs - 1) * 2048;
+                                r0h[(u + D - 1) % D].f = ld_w16(rA, lane16, off);
+                                r0l[(u + D - 1) % D].f = ld_w16(rA, lane16, off + 1024);
+                                r1h[(u + D - 1) % D].f = ld_w16(rA, lane16, a1 + off);
+                                r1l[(u + D - 1) % D].f = ld_w16(rA, lane16, a1 + off + 1024);
                             }
                             __builtin_amdgcn_sched_barrier(0);
                             block(t, r0h[u], r0l[u], r1h[u], r1l[u]);
