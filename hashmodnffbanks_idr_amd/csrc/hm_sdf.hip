@@ -228,11 +228,14 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_kernel(HmLevels lv, Sd
                 const float *src1 = (Ly.seg_src[1] == 0) ? X : EMB;
                 if (!ring_ready) prefetch64(li);
                 ring_ready = false;
-                auto octet = [&](int gg, const float4 &a0, const float4 &a1) {
-                    const float *src = (gg < no0) ? src0 + (2 * gg + h) * kGroupFloats
-                                                  : src1 + (2 * (gg - no0) + h) * kGroupFloats;
-                    const float4 b0 = *reinterpret_cast<const float4 *>(src + j * 4);
-                    const float4 b1 = *reinterpret_cast<const float4 *>(src + (32 + j) * 4);
+                auto loadB = [&](int gg, float4 &b0, float4 &b1) {
+                    const int gc = min(gg, n_oct - 1);
+                    const float *src = (gc < no0) ? src0 + (2 * gc + h) * kGroupFloats
+                                                  : src1 + (2 * (gc - no0) + h) * kGroupFloats;
+                    b0 = *reinterpret_cast<const float4 *>(src + j * 4);
+                    b1 = *reinterpret_cast<const float4 *>(src + (32 + j) * 4);
+                };
+                auto mfma16 = [&](const float4 &a0, const float4 &a1, const float4 &b0, const float4 &b1) {
                     acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc00, 0, 0, 0);
                     acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b1.x, acc01, 0, 0, 0);
                     acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, acc10, 0, 0, 0);
@@ -250,9 +253,11 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_kernel(HmLevels lv, Sd
                     acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b0.w, acc10, 0, 0, 0);
                     acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc11, 0, 0, 0);
                 };
-                // (requesting the B fragments of octet gg + 1 before octet gg's MFMAs - two register sets - shortens ONE
-                //  wave's k-loop from 62.4 to 54.2 us per 512 x 512 layer but not the layer: the wave then waits 11 us at
-                //  the barrier for the SIMD's other wave; the matrix pipe is the limit, scripts/sdf_phase_probe.py)
+                // (full tiles request the B fragments of octet gg + 1 before octet gg's MFMAs - two register sets, loadB / mfma16:
+                //  with the ds_reads behind the scheduling barrier of their own octet every octet starts with an exposed
+                //  LDS round trip.  Alone this changed nothing - one wave's k-loop 62.4 -> 54.2 us per layer, but then 11 us
+                //  at the barrier, scripts/sdf_phase_probe.py; on top of the buffer-load weight stream: 132.0 -> 134.2
+                //  TFLOP/s)
                 // whole groups of four octets run without an exit test: with a `break` inside the unrolled group
                 // hipcc cannot count the loads in flight across the back edge and drains them (vmcnt(0)) at every
                 // loop head; the 1-3 left-over octets are already in ring slots 0..2
@@ -272,6 +277,8 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_kernel(HmLevels lv, Sd
                 };
                 const int n_full = n_oct & ~3;
                 if (!half) {
+                    float4 bA0, bA1, bB0, bB1;      // B fragments: even octets in set A, odd octets in set B
+                    loadB(0, bA0, bA1);
                     for (int gg0 = 0; gg0 < n_full; gg0 += 4) {
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
@@ -281,13 +288,14 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_kernel(HmLevels lv, Sd
                                 r0[(u + 3) & 3] = ldw(rsA, off);
                                 r1[(u + 3) & 3] = ldw(rsA, tA1 + off);
                             }
+                            if (u & 1) loadB(gg + 1, bA0, bA1); else loadB(gg + 1, bB0, bB1);
                             __builtin_amdgcn_sched_barrier(0);   // (loads stay ahead of this octet's MFMAs; see the 16-point body)
-                            octet(gg, r0[u], r1[u]);
+                            if (u & 1) mfma16(r0[u], r1[u], bB0, bB1); else mfma16(r0[u], r1[u], bA0, bA1);
                         }
                     }
-                    if (n_full + 0 < n_oct) octet(n_full + 0, r0[0], r1[0]);
-                    if (n_full + 1 < n_oct) octet(n_full + 1, r0[1], r1[1]);
-                    if (n_full + 2 < n_oct) octet(n_full + 2, r0[2], r1[2]);
+                    if (n_full + 0 < n_oct) { loadB(n_full + 1, bB0, bB1); mfma16(r0[0], r1[0], bA0, bA1); }
+                    if (n_full + 1 < n_oct) { loadB(n_full + 2, bA0, bA1); mfma16(r0[1], r1[1], bB0, bB1); }
+                    if (n_full + 2 < n_oct) mfma16(r0[2], r1[2], bA0, bA1);
                 } else {
                     for (int gg0 = 0; gg0 < n_full; gg0 += 4) {
 #pragma unroll
@@ -759,10 +767,15 @@ __device__ __forceinline__ void sdf_m16_body(const HmLevels &lv, const SdfNet &n
                 const float *src1 = (Ly.seg_src[1] == 0) ? X : EMB;
                 if (!ring_ready) prefetch16(li);
                 ring_ready = false;
-                auto block16 = [&](int t, const float4 (&w)[4]) {
-                    const float *src = (t < nb0) ? src0 + (4 * t + q) * kGroupFloats16
-                                                 : src1 + (4 * (t - nb0) + q) * kGroupFloats16;
-                    const float4 b = *reinterpret_cast<const float4 *>(src + j * 4);
+                // B fragment of k-block t (LDS), requested one block ahead of its MFMAs (two registers sets, as in the
+                // 64-point kernel)
+                auto loadB16 = [&](int t) -> float4 {
+                    const int tc = min(t, nb - 1);
+                    const float *src = (tc < nb0) ? src0 + (4 * tc + q) * kGroupFloats16
+                                                  : src1 + (4 * (tc - nb0) + q) * kGroupFloats16;
+                    return *reinterpret_cast<const float4 *>(src + j * 4);
+                };
+                auto block16 = [&](const float4 &b, const float4 (&w)[4]) {
                     // component-major order: four INDEPENDENT accumulators between two uses of the same one
 #pragma unroll
                     for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[a].x, b.x, acc[a], 0, 0, 0);
@@ -777,6 +790,8 @@ __device__ __forceinline__ void sdf_m16_body(const HmLevels &lv, const SdfNet &n
                 // hipcc drains all loads in flight - vmcnt(0) - at every loop head); the left-over blocks are
                 // already in ring slots 0 .. kRing16-2
                 const int nb_full = (nb / kRing16) * kRing16;
+                static_assert(kRing16 % 2 == 0, "the B double buffer alternates with the parity of the block in the group");
+                float4 bE = loadB16(0), bO;      // even / odd blocks
                 for (int tt = 0; tt < nb_full; tt += kRing16) {
 #pragma unroll
                     for (int u = 0; u < kRing16; ++u) {
@@ -790,13 +805,17 @@ __device__ __forceinline__ void sdf_m16_body(const HmLevels &lv, const SdfNet &n
                         }
                         // keep the four loads HERE: left to itself hipcc sinks them below this block's MFMAs (their
                         // destination registers double as MFMA temporaries), which halves the bytes in flight
+                        if (u & 1) bE = loadB16(t + 1); else bO = loadB16(t + 1);
                         __builtin_amdgcn_sched_barrier(0);
-                        block16(t, ring[u]);
+                        if (u & 1) block16(bO, ring[u]); else block16(bE, ring[u]);
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < kRing16 - 1; ++u)
-                    if (nb_full + u < nb) block16(nb_full + u, ring[u]);
+                for (int u = 0; u < kRing16 - 1; ++u)      // (nb_full is even: block nb_full + u has the parity of u)
+                    if (nb_full + u < nb) {
+                        if (u & 1) { bE = loadB16(nb_full + u + 1); block16(bO, ring[u]); }
+                        else { bO = loadB16(nb_full + u + 1); block16(bE, ring[u]); }
+                    }
             }
             // request the next layer's first blocks now: they travel while this layer's epilogue and the two
             // barriers run (weights do not depend on the activations)
