@@ -49,9 +49,15 @@ __device__ unsigned long long hm_probe_ts[128];
     do {                                                                                                       \
         if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && it == 1 && li == 2) hm_probe_ts[(base_) + (threadIdx.x >> 6)] = wall_clock64(); \
     } while (0)
+// small-tile bodies: workgroup 0 / thread 0 stamps of its first tile -> ts[i]
+#define HM_PROBE_S(i_)                                                                                \
+    do {                                                                                              \
+        if (blockIdx.x == 0 && threadIdx.x == 0 && (i_) < 120) hm_probe_ts[(i_)] = wall_clock64();   \
+    } while (0)
 #else
 #define HM_PROBE(i_) do { } while (0)
 #define HM_PROBE_WAVES(base_) do { } while (0)
+#define HM_PROBE_S(i_) do { } while (0)
 #endif
 
 constexpr int kPts = 64;        // points per workgroup tile
@@ -907,6 +913,7 @@ __device__ __forceinline__ void sdf_m8_body(const HmLevels &lv, const SdfNet &ne
     for (int64_t tile = tile_first; tile < n_tiles; tile += tile_step) {
         const int64_t base = tile * PTS;
         const int cnt = (int)min((int64_t)PTS, n - base);
+        HM_PROBE_S(0);
         __syncthreads();
         if (FRAC != kFracEmb && tid < kPts8 * 3) SX[tid] = (tid < cnt * 3) ? x[base * 3 + tid] : 0.0f;
         __syncthreads();
@@ -955,6 +962,7 @@ __device__ __forceinline__ void sdf_m8_body(const HmLevels &lv, const SdfNet &ne
             }
         }
         __syncthreads();
+        HM_PROBE_S(1);
 
         float4 ring[RD8][4];
         bool ring_ready = false;
@@ -1069,6 +1077,7 @@ __device__ __forceinline__ void sdf_m8_body(const HmLevels &lv, const SdfNet &ne
                     ring_ready = true;
                 }
             }
+            HM_PROBE_S(2 + 4 * li);
             // add the four k quarters; lane q ends up with the complete sums of feature tile a == q
             // (exchange across lane bit 5 keeps tiles {0,1} or {2,3}, across bit 4 keeps one of the pair)
             f32x4 r0, r1;
@@ -1093,7 +1102,9 @@ __device__ __forceinline__ void sdf_m8_body(const HmLevels &lv, const SdfNet &ne
                     r1[r] = TWO ? keep1 + __shfl_xor(send1, 16) : 0.0f;
                 }
             }
+            HM_PROBE_S(3 + 4 * li);
             __syncthreads();
+            HM_PROBE_S(4 + 4 * li);
             const bool act = Ly.activation != 0;
             const bool div = Ly.post_div_sqrt2 != 0;
             const float sqrt2 = 1.41421356237309515f;
@@ -1117,7 +1128,9 @@ __device__ __forceinline__ void sdf_m8_body(const HmLevels &lv, const SdfNet &ne
                 for (int i = tid; i < emb_groups16 * kGroupFloats8; i += kThreadsSdf) EMB[i] = __fdiv_rn(EMB[i], sqrt2);
             }
             __syncthreads();
+            HM_PROBE_S(5 + 4 * li);
         }
+        HM_PROBE_S(100);
 
         const hm_mlp_layer &last = net.layer[net.n_layers - 1];
         if (out_cols != 1) {
