@@ -32,6 +32,7 @@ struct GemmArgs {
     int32_t k_chunk;  // K range handled by one blockIdx.z
     int32_t atomic;   // accumulate with atomics (split-K, or beta = 1)
     int32_t vecA, vecB;  // operand may be fetched with aligned 16-B loads
+    int32_t nrecA, nrecB;  // pipelined kernel: bytes of the operands' buffer descriptors (reads beyond them return 0)
     hm_gemm_epilogue ep;  // fused elementwise epilogue (mode HM_EPI_NONE = plain store)
 };
 
@@ -428,8 +429,11 @@ __device__ __forceinline__ void gemm_pipe2_body(const GemmArgs &g, int bx, int b
     // VGPR, the stage's offset scalar - no 64-bit address arithmetic on the VALU inside the loop (VALU instructions are
     // serial with the MFMAs of every wave on the SIMD; the fused SDF kernels gained 3 - 11 % from the same change).
     // The host takes this kernel only for operands below 2 GB.
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.A), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.B), 0, 0x7fffffff, 0x00020000);
+    // The descriptors end at the operands' last element: a K range that is no multiple of the stage group (K = 445, 257)
+    // runs to the next multiple, the operand whose k is the SLOW dimension returns zeros beyond its end and cancels what the
+    // k-contiguous one reads from its following rows (the host admits a K tail only when there is such an operand).
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.A), 0, g.nrecA, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.B), 0, g.nrecB, 0x00020000);
     int va[PER], vb[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
@@ -547,6 +551,7 @@ __global__ __launch_bounds__(512, 4) void gemm_f32_pipe2_group_kernel(GemmGroupT
     g.k_chunk = E.k_chunk;
     g.atomic = 1;
     g.vecA = g.vecB = 0;
+    g.nrecA = g.nrecB = 0x7fffffff;
     g.ep.mode = HM_EPI_NONE;
     gemm_pipe2_body<false, false, false>(g, bx, by, bz);
 }
@@ -614,11 +619,22 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K, co
     static const int pipe_cfg = [] { const char *e = getenv("HM_GEMM_PIPE"); return e ? atoi(e) : 2; }();   // 2 = eight-wave variant
     // the pipelined kernel takes K ranges that are a whole number of 128-deep groups per split and operands that are
     // either k-contiguous + 16-B aligned or row-contiguous (partial edge tiles are fine: clamped rows, guarded stores)
-    // (pipe_cfg 2 fetches through buffer descriptors with 32-bit offsets: operands below 2 GB)
-    const int64_t bytesA = 4 * lda * (transA ? K : M), bytesB = 4 * ldb * (transB ? N : K);
-    const bool use_pipe = !big && small_cfg == 0 && !half_rows && pipe_cfg != 0 &&
-                          K % (kPipeBK * kPipeD) == 0 && K > 0 && (!a_kc || g.vecA) && (!b_kc || g.vecB) &&
-                          (pipe_cfg != 2 || (bytesA < (1ll << 31) && bytesB < (1ll << 31)));
+    // pipe_cfg 2 fetches through buffer descriptors with 32-bit offsets (operands below 2 GB); its 16-byte loads need
+    // dword alignment only (probed: unaligned buffer_load_dwordx4 returns the right dwords), so k-contiguous operands with
+    // any leading dimension qualify, and a K TAIL is admitted when one operand has k as its slow dimension: the K range
+    // runs to the next multiple of the stage group, that operand's descriptor returns zeros beyond its end (K = 445 and
+    // 257 of the backward sweeps: 27 - 43 us on the generic kernel).  HM_GEMM_KTAIL=0: generic kernel for those (A/B).
+    const int64_t bytesA = 4 * ((transA ? K - 1 : M - 1) * lda + (transA ? M : K)),
+                  bytesB = 4 * ((transB ? N - 1 : K - 1) * ldb + (transB ? K : N));
+    static const int ktail_cfg = [] { const char *e = getenv("HM_GEMM_KTAIL"); return e ? atoi(e) : 1; }();
+    const bool buf_ok = pipe_cfg == 2 && bytesA < (1ll << 31) && bytesB < (1ll << 31);
+    const bool k_whole = K % (kPipeBK * kPipeD) == 0;
+    // (K >= 192: below that the rounded-up range costs more than the generic kernel's guards - K = 72 of the filter banks)
+    const bool k_tail_ok = buf_ok && ktail_cfg != 0 && (!a_kc || !b_kc) && K >= 192;
+    const bool use_pipe = !big && small_cfg == 0 && !half_rows && pipe_cfg != 0 && K > 0 &&
+                          (buf_ok ? (k_whole || k_tail_ok) : (k_whole && (!a_kc || g.vecA) && (!b_kc || g.vecB)));
+    g.nrecA = (int32_t)(bytesA < 0x7fffffff ? bytesA : 0x7fffffff);
+    g.nrecB = (int32_t)(bytesB < 0x7fffffff ? bytesB : 0x7fffffff);
     // 96-row tiles when they need fewer rounds of the chip per row of the tile (M = 3072, N = 512: 384 tiles of 64 rows -
     // the slowest CU runs two = 128 rows' worth - against 256 tiles of 96).  HM_GEMM_M96=0: always 64-row tiles (A/B).
     static const int m96_cfg = [] { const char *e = getenv("HM_GEMM_M96"); return e ? atoi(e) : 1; }();
@@ -628,7 +644,8 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K, co
     const int64_t kBK = big ? 32 : (use_pipe ? kPipeBK * kPipeD : (small_cfg == 1 || small_cfg == 2 ? 64 : 128));
     const int64_t tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
     int64_t split = 1;
-    if (tiles < 256 && K >= 256 && g.ep.mode == HM_EPI_NONE) {   // (a nonlinear epilogue needs the full sum)
+    if (tiles < 256 && K >= 256 && g.ep.mode == HM_EPI_NONE && !(use_pipe && !k_whole)) {   // (a nonlinear epilogue needs the
+                                                                                          // full sum; a K tail is not split)
         static const int split_target = [] { const char *e = getenv("HM_GEMM_SPLIT_TARGET"); return e ? atoi(e) : 512; }();
         split = (split_target + tiles - 1) / tiles;
         const int64_t max_split = K / 128;
@@ -639,10 +656,11 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K, co
     k_chunk = ((k_chunk + kBK - 1) / kBK) * kBK;
     if (k_chunk == 0) k_chunk = kBK;
     // the pipelined kernel has no K tail: grow the chunk until it divides K (K = 6144 over 10 splits: 640 -> 768)
-    while (use_pipe && K % k_chunk != 0 && k_chunk < K) k_chunk += kBK;
+    while (use_pipe && k_whole && K % k_chunk != 0 && k_chunk < K) k_chunk += kBK;
     split = K > 0 ? (K + k_chunk - 1) / k_chunk : 1;
     g.k_chunk = (int)k_chunk;
-    const bool pipe_ok = use_pipe && K % k_chunk == 0;   // (the pipelined kernel has no K-tail handling)
+    // (whole K: the chunks divide it; K tail: ONE chunk of the rounded-up K, zeros beyond the slow operand's end)
+    const bool pipe_ok = use_pipe && (k_whole ? K % k_chunk == 0 : split == 1);
     g.atomic = (accumulate || split > 1) ? 1 : 0;
     if (split > 1 && !accumulate) {
         // split-K accumulates with atomics into a zeroed C

@@ -23,8 +23,10 @@ def _close(got, ref, what):
 
 
 # (3072 / 2700 rows: the 96 x 64 tile of the pipelined kernel - whole and with a ragged last row tile, 445 = ragged columns)
+# (K = 445 / 257: the pipelined kernel's K tail - the k range runs to the next multiple of 128, the operand with k as its
+#  slow dimension returns zeros beyond its end - in the NN form of the backward sweeps; their NT forms stay on the generic kernel)
 @pytest.mark.parametrize("M,N,K", [(300, 445, 67), (2100, 512, 512), (64, 257, 512), (1, 5, 3), (3072, 512, 512),
-                                   (2700, 445, 512)])
+                                   (2700, 445, 512), (3072, 512, 445), (2048, 512, 257), (100, 130, 190)])
 def test_gemm_epilogues(M, N, K):
     from hashmodnffbanks_idr_amd import ops
     g = torch.Generator(device="cpu").manual_seed(M + N + K)

@@ -170,7 +170,8 @@ def test_gemm_shapes_vs_torch():
     from hashmodnffbanks_idr_amd import ops
     rs = np.random.RandomState(0)
     for (M, N, K) in [(1, 1, 1), (100, 445, 67), (300, 257, 512), (64, 64, 16), (513, 130, 33), (2048, 512, 512),
-                      (3072, 445, 512), (2700, 512, 512), (130, 67, 256), (445, 512, 1024), (65, 1, 128)]:
+                      (3072, 445, 512), (2700, 512, 512), (130, 67, 256), (445, 512, 1024), (65, 1, 128),
+                      (3072, 512, 445), (2048, 512, 257), (777, 300, 190)]:
         a = torch.from_numpy(rs.standard_normal((M, K)).astype(np.float32)).cuda()
         b = torch.from_numpy(rs.standard_normal((K, N)).astype(np.float32)).cuda()
         bias = torch.from_numpy(rs.standard_normal(N).astype(np.float32)).cuda()
