@@ -637,8 +637,11 @@ __device__ __forceinline__ void sdf_m16_body(const HmLevels &lv, const SdfNet &n
                                              int64_t out_stride, int out_cols, float *lds, int64_t tile_first,
                                              int64_t tile_step) {
     const int emb_groups16 = ((lv.E + 15) / 16) * 4;
-    float *X = lds;
-    float *EMB = lds + (size_t)net.x_groups * kGroupFloats16;
+    // two activation images, used alternately (layer l reads one, its epilogue writes the other): no barrier between a
+    // layer's k-loop and its epilogue - a wave that finishes early does not wait for the others before its Softplus
+    float *X0 = lds;
+    float *X1 = lds + (size_t)net.x_groups * kGroupFloats16;
+    float *EMB = X1 + (size_t)net.x_groups * kGroupFloats16;
     float *SX = EMB + (size_t)emb_groups16 * kGroupFloats16;  // [16][3]
     float *RED = SX + kPts16 * 4;                              // [8][16]
 
@@ -654,6 +657,7 @@ __device__ __forceinline__ void sdf_m16_body(const HmLevels &lv, const SdfNet &n
     for (int64_t tile = tile_first; tile < n_tiles; tile += tile_step) {
         const int64_t base = tile * kPts16;
         const int cnt = (int)min((int64_t)kPts16, n - base);
+        float *X = X0, *Xn = X1;     // X: the image the current layer reads; Xn: the one its epilogue fills
         __syncthreads();
         if (FRAC != kFracEmb && tid < kPts16 * 3) SX[tid] = (tid < cnt * 3) ? x[base * 3 + tid] : 0.0f;
         __syncthreads();
@@ -831,7 +835,7 @@ __device__ __forceinline__ void sdf_m16_body(const HmLevels &lv, const SdfNet &n
                     ring_ready = true;
                 }
             }
-            __syncthreads();
+            if (li == 0) __syncthreads();   // (layer 0 only: its epilogue rescales EMB in place, which every wave has read)
             const bool act = Ly.activation != 0;
             const bool div = Ly.post_div_sqrt2 != 0;
             const float sqrt2 = 1.41421356237309515f;
@@ -848,12 +852,13 @@ __device__ __forceinline__ void sdf_m16_body(const HmLevels &lv, const SdfNet &n
                     v0 = __fdiv_rn(v0, sqrt2); v1 = __fdiv_rn(v1, sqrt2); v2 = __fdiv_rn(v2, sqrt2);
                     v3 = __fdiv_rn(v3, sqrt2);
                 }
-                *reinterpret_cast<float4 *>(X + (f >> 2) * kGroupFloats16 + j * 4) = make_float4(v0, v1, v2, v3);
+                *reinterpret_cast<float4 *>(Xn + (f >> 2) * kGroupFloats16 + j * 4) = make_float4(v0, v1, v2, v3);
             }
             if (li == 0) {
                 for (int i = tid; i < emb_groups16 * kGroupFloats16; i += kThreadsSdf) EMB[i] = __fdiv_rn(EMB[i], sqrt2);
             }
             __syncthreads();
+            { float *t_ = X; X = Xn; Xn = t_; }
         }
 
         const hm_mlp_layer &last = net.layer[net.n_layers - 1];
@@ -893,8 +898,11 @@ __device__ __forceinline__ void sdf_m8_body(const HmLevels &lv, const SdfNet &ne
                                             int64_t out_stride, int out_cols, float *lds, int64_t tile_first,
                                             int64_t tile_step) {
     const int emb_groups16 = ((lv.E + 15) / 16) * 4;
-    float *X = lds;
-    float *EMB = lds + (size_t)net.x_groups * kGroupFloats8;
+    // two activation images, used alternately (layer l reads one, its epilogue writes the other): no barrier between a
+    // layer's k-loop and its epilogue - a wave that finishes early does not wait for the others before its Softplus
+    float *X0 = lds;
+    float *X1 = lds + (size_t)net.x_groups * kGroupFloats8;
+    float *EMB = X1 + (size_t)net.x_groups * kGroupFloats8;
     float *SX = EMB + (size_t)emb_groups16 * kGroupFloats8;  // [8][3] (+ pad)
     float *RED = SX + kPts8 * 4;                              // [8 waves][8 points]
 
@@ -914,6 +922,7 @@ __device__ __forceinline__ void sdf_m8_body(const HmLevels &lv, const SdfNet &ne
         const int64_t base = tile * PTS;
         const int cnt = (int)min((int64_t)PTS, n - base);
         HM_PROBE_S(0);
+        float *X = X0, *Xn = X1;     // X: the image the current layer reads; Xn: the one its epilogue fills
         __syncthreads();
         if (FRAC != kFracEmb && tid < kPts8 * 3) SX[tid] = (tid < cnt * 3) ? x[base * 3 + tid] : 0.0f;
         __syncthreads();
@@ -1103,7 +1112,7 @@ __device__ __forceinline__ void sdf_m8_body(const HmLevels &lv, const SdfNet &ne
                 }
             }
             HM_PROBE_S(3 + 4 * li);
-            __syncthreads();
+            if (li == 0) __syncthreads();   // (layer 0 only: its epilogue rescales EMB in place, which every wave has read)
             HM_PROBE_S(4 + 4 * li);
             const bool act = Ly.activation != 0;
             const bool div = Ly.post_div_sqrt2 != 0;
@@ -1120,7 +1129,7 @@ __device__ __forceinline__ void sdf_m8_body(const HmLevels &lv, const SdfNet &ne
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
                     if (div) v[i] = __fdiv_rn(v[i], sqrt2);
-                float *dst = X + (f >> 2) * kGroupFloats8;
+                float *dst = Xn + (f >> 2) * kGroupFloats8;
                 *reinterpret_cast<float4 *>(dst + p4 * 4) = make_float4(v[0], v[1], v[2], v[3]);
                 if (TWO) *reinterpret_cast<float4 *>(dst + (p4 + 4) * 4) = make_float4(v[4], v[5], v[6], v[7]);
             }
@@ -1128,6 +1137,7 @@ __device__ __forceinline__ void sdf_m8_body(const HmLevels &lv, const SdfNet &ne
                 for (int i = tid; i < emb_groups16 * kGroupFloats8; i += kThreadsSdf) EMB[i] = __fdiv_rn(EMB[i], sqrt2);
             }
             __syncthreads();
+            { float *t_ = X; X = Xn; Xn = t_; }
             HM_PROBE_S(5 + 4 * li);
         }
         HM_PROBE_S(100);
@@ -1341,9 +1351,19 @@ int hm_trace_march_tail(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const 
     if (a.n == 0 || first >= rounds) return HM_OK;
     HM_CHECK_ARG(a.w.cap >= ((a.n + 7) / 8) * 16, "hm_trace_march_tail: point buffer too small");
     const int emb_b16 = (desc->lv.E + 15) / 16;
-    const int lds_floats = (net.x_groups + emb_b16 * 4) * kGroupFloats16 + kPts16 * 4 + kWaves * kPts16;
+    const int lds_floats = (2 * net.x_groups + emb_b16 * 4) * kGroupFloats16 + kPts16 * 4 + kWaves * kPts16;   // two activation images
     const size_t lds = sizeof(float) * (size_t)lds_floats + 64;
-    HM_CHECK_ARG(lds <= 64 * 1024, "hm_trace_march_tail: network does not fit the 16-point LDS tile");
+    HM_CHECK_ARG(lds <= 96 * 1024, "hm_trace_march_tail: network does not fit the 16-point LDS tile");
+    static thread_local bool attr_tail_done = false;
+    if (!attr_tail_done) {  // opt in to >64 KB dynamic LDS once (not a stream operation)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(trace_march_tail_kernel<HM_FRAC_REFERENCE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(trace_march_tail_kernel<HM_FRAC_TRILINEAR>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) return hm_fail(HM_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+        attr_tail_done = true;
+    }
     const unsigned grid = (unsigned)((a.n + 7) / 8);
     if (frac_mode == HM_FRAC_REFERENCE)
         hipLaunchKernelGGL(trace_march_tail_kernel<HM_FRAC_REFERENCE>, dim3(grid), dim3(kThreadsSdf), lds,
@@ -1412,13 +1432,23 @@ static int sdf_fwd_impl(const HmLevels &lv, const hm_mlp_desc *mlp, const float 
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(sdf_fwd_kernel<kFracEmb>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        // (small tiles: two activation images of 32 KB + the embedding = 70 KB at 512-wide layers)
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(sdf_fwd_small_kernel<HM_FRAC_REFERENCE>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(sdf_fwd_small_kernel<HM_FRAC_TRILINEAR>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(sdf_fwd_small_kernel<kFracEmb>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         if (e != hipSuccess) return hm_fail(HM_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
         attr_done = true;
     }
     if (run16) {
-        const size_t lds = sizeof(float) * ((size_t)(net.x_groups + emb_b16 * 4) * kGroupFloats16 + kPts16 * 4 +
-                                            kWaves * kPts16);   // (the 8-point layout needs half of this)
-        HM_CHECK_ARG(lds <= 64 * 1024, "hm_sdf_fwd: network does not fit the 16-point LDS tile");
+        const size_t lds = sizeof(float) * ((size_t)(2 * net.x_groups + emb_b16 * 4) * kGroupFloats16 + kPts16 * 4 +
+                                            kWaves * kPts16);   // two activation images (the 8-point layout needs half of this)
+        HM_CHECK_ARG(lds <= 96 * 1024, "hm_sdf_fwd: network does not fit the 16-point LDS tile");
         const int64_t nmax = n < hi16 ? n : hi16;
         int64_t tiles = m8_max >= nmax ? 0 : (nmax + kPts16 - 1) / kPts16;
         if (m8_max > 0) {
