@@ -1250,6 +1250,42 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void mfma_f32_stream_kernel(int ite
     out[(size_t)blockIdx.x * kThreadsSdf + threadIdx.x] = acc00[0] + acc01[5] + acc10[9] + acc11[15];
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Persistent secant refinement (reference: model/ray_tracing.py:251-268): the secant rays are a compact list, a tile
+// of them (4 / 8 / 16 by the list's length - the rule of sdf_fwd_small_kernel, so the values are those of one
+// hm_sdf_fwd launch per iteration) stays with its workgroup through all iterations: evaluate the tile's midpoints, run
+// secant_advance_ray for its rays, repeat.  Nothing is exchanged between workgroups: 8 (SDF launch, update launch) pairs
+// become one launch.
+__device__ __attribute__((noinline)) void secant_step_ray(const TraceArgs &a, int64_t q, int last) {
+    secant_advance_ray(a, q, last);
+}
+
+template <int FRAC>
+__global__ __launch_bounds__(kThreadsSdf, 1) void trace_secant_kernel(HmLevels lv, SdfNet net,
+                                                                       const float *__restrict__ table,
+                                                                       const float *__restrict__ Bf, TraceArgs a,
+                                                                       int n_iters, int64_t m8_max, int64_t m4_max) {
+    extern __shared__ __align__(16) float lds[];
+    const int64_t n = a.w.cnt[C_NSEC];
+    if (n <= 0) return;
+    const int pts = n <= m4_max ? 4 : (n <= m8_max ? 8 : 16);
+    const int64_t n_tiles = (n + pts - 1) / pts;
+    for (int it = 0; it < n_iters; ++it) {
+        if (pts == 4)
+            sdf_m8_body<FRAC, 4>(lv, net, a.w.pts, n, table, Bf, a.w.vals, 1, 1, lds, blockIdx.x, gridDim.x);
+        else if (pts == 8)
+            sdf_m8_body<FRAC, 8>(lv, net, a.w.pts, n, table, Bf, a.w.vals, 1, 1, lds, blockIdx.x, gridDim.x);
+        else
+            sdf_m16_body<FRAC>(lv, net, a.w.pts, n, table, Bf, a.w.vals, 1, 1, lds, blockIdx.x, gridDim.x);
+        __syncthreads();       // the tile's values (global stores of this workgroup) are visible to its threads
+        for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+            const int64_t q = tile * pts + threadIdx.x;
+            if ((int)threadIdx.x < pts && q < n) secant_step_ray(a, q, it == n_iters - 1 ? 1 : 0);
+        }
+        __syncthreads();       // the next iteration's points are written
+    }
+}
+
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 }  // namespace
@@ -1372,6 +1408,56 @@ int hm_trace_march_tail(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const 
         hipLaunchKernelGGL(trace_march_tail_kernel<HM_FRAC_TRILINEAR>, dim3(grid), dim3(kThreadsSdf), lds,
                            as_stream(stream), desc->lv, net, table, B_fourier, a, first, rounds, lds_floats);
     HM_CHECK_LAUNCH("hm_trace_march_tail");
+    return HM_OK;
+}
+
+// internal entry of the ray search (hm_trace.hip, not exported): all secant iterations as ONE launch
+// (trace_secant_kernel).  tile_points 0 = the tile size follows the list's length as in hm_sdf_fwd; 4 / 8 / 16 = fixed.
+int hm_trace_secant_persistent(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *table, const float *B_fourier,
+                               int frac_mode, int tile_points, const void *trace_args, int n_iters, void *stream) {
+    HM_CHECK_ARG(desc && mlp && table && B_fourier && trace_args, "hm_trace_secant_persistent: NULL argument");
+    HM_CHECK_ARG(frac_mode == HM_FRAC_REFERENCE || frac_mode == HM_FRAC_TRILINEAR, "hm_trace_secant_persistent: bad frac_mode");
+    HM_CHECK_ARG(tile_points == 0 || tile_points == 4 || tile_points == 8 || tile_points == 16,
+                 "hm_trace_secant_persistent: tile_points must be 0, 4, 8 or 16");
+    const TraceArgs &a = *static_cast<const TraceArgs *>(trace_args);
+    SdfNet net;
+    bool have16 = false;
+    const int rc = sdf_net_from_desc(desc->lv, mlp, 0, net, have16);
+    if (rc != HM_OK) return rc;
+    HM_CHECK_ARG(have16, "hm_trace_secant_persistent: needs w_packed_m16 in every layer");
+    if (a.n == 0 || n_iters <= 0) return HM_OK;
+    const int64_t kBig = (int64_t)1 << 62;
+    int64_t m8_max = 0, m4_max = 0;      // (the thresholds of hm_sdf_fwd's small-tile launch)
+    if (tile_points == 0) { m8_max = 2048; m4_max = 1024; }
+    else if (tile_points == 8) m8_max = kBig;
+    else if (tile_points == 4) { m8_max = kBig; m4_max = kBig; }
+    const int emb_b16 = (desc->lv.E + 15) / 16;
+    const size_t lds = sizeof(float) * ((size_t)(2 * net.x_groups + emb_b16 * 4) * kGroupFloats16 + kPts16 * 4 +
+                                        kWaves * kPts16);
+    HM_CHECK_ARG(lds <= 96 * 1024, "hm_trace_secant_persistent: network does not fit the 16-point LDS tile");
+    static thread_local bool attr_sec_done = false;
+    if (!attr_sec_done) {  // opt in to >64 KB dynamic LDS once (not a stream operation)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(trace_secant_kernel<HM_FRAC_REFERENCE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(trace_secant_kernel<HM_FRAC_TRILINEAR>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) return hm_fail(HM_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+        attr_sec_done = true;
+    }
+    // workgroups for the longest list the call can see (every ray a secant ray), one tile each up to one per CU
+    const int64_t nmax = a.n;
+    int64_t tiles = m8_max >= nmax ? 0 : (nmax + kPts16 - 1) / kPts16;
+    if (m8_max > 0) tiles = max(tiles, ((nmax < m8_max ? nmax : m8_max) + kPts8 - 1) / kPts8);
+    if (m4_max > 0) tiles = max(tiles, ((nmax < m4_max ? nmax : m4_max) + 3) / 4);
+    const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
+    if (frac_mode == HM_FRAC_REFERENCE)
+        hipLaunchKernelGGL(trace_secant_kernel<HM_FRAC_REFERENCE>, dim3(grid), dim3(kThreadsSdf), lds, as_stream(stream),
+                           desc->lv, net, table, B_fourier, a, n_iters, m8_max, m4_max);
+    else
+        hipLaunchKernelGGL(trace_secant_kernel<HM_FRAC_TRILINEAR>, dim3(grid), dim3(kThreadsSdf), lds, as_stream(stream),
+                           desc->lv, net, table, B_fourier, a, n_iters, m8_max, m4_max);
+    HM_CHECK_LAUNCH("hm_trace_secant_persistent");
     return HM_OK;
 }
 

@@ -22,6 +22,10 @@ extern "C" int hm_trace_march_tail(const hm_grid_desc *desc, const hm_mlp_desc *
                                    const float *B_fourier, int frac_mode, const void *trace_args, int first, int rounds,
                                    void *stream);
 
+extern "C" int hm_trace_secant_persistent(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *table,
+                                          const float *B_fourier, int frac_mode, int tile_points, const void *trace_args,
+                                          int n_iters, void *stream);
+
 namespace {
 
 constexpr int kTB = 256;
@@ -91,11 +95,6 @@ __global__ __launch_bounds__(kTB) void ray_samples_kernel(TraceArgs a, const int
     along(a, i, t, px, py, pz);
     const int64_t o = base + gid;
     w.pts[o * 3] = px; w.pts[o * 3 + 1] = py; w.pts[o * 3 + 2] = pz;
-}
-
-__device__ __forceinline__ float secant_z(float v_lo, float v_hi, float z_lo, float z_hi) {
-    // - sdf_low * (z_high - z_low) / (sdf_high - sdf_low) + z_low, evaluated left to right
-    return __fadd_rn(__fdiv_rn(__fmul_rn(-v_lo, __fsub_rn(z_hi, z_lo)), __fsub_rn(v_hi, v_lo)), z_lo);
 }
 
 // lazy sampler, between the passes: a ray is resolved by its head samples iff one of them is negative and the ray is
@@ -205,28 +204,11 @@ __global__ __launch_bounds__(kTB) void secant_points_kernel(TraceArgs a) {
     w.pts[q * 3] = px; w.pts[q * 3 + 1] = py; w.pts[q * 3 + 2] = pz;
 }
 
-// one secant iteration (ray_tracing.py:255-266); the last one writes the refined hit
+// one secant iteration (ray_tracing.py:255-266), stand-alone form of secant_advance_ray
 __global__ __launch_bounds__(kTB) void secant_advance_kernel(TraceArgs a, int last) {
     const int64_t q = (int64_t)blockIdx.x * kTB + threadIdx.x;
-    const TraceWs &w = a.w;
-    if (q >= w.cnt[C_NSEC]) return;
-    const float v = w.vals[q];
-    if (!isfinite(v)) atomicAdd(w.cnt + C_NONFINITE, 1);
-    float z = w.z[q], z_lo = w.z_lo[q], z_hi = w.z_hi[q], v_lo = w.v_lo[q], v_hi = w.v_hi[q];
-    if (v > 0.0f) { z_lo = z; v_lo = v; }
-    if (v < 0.0f) { z_hi = z; v_hi = v; }
-    z = secant_z(v_lo, v_hi, z_lo, z_hi);
-    w.z[q] = z; w.z_lo[q] = z_lo; w.z_hi[q] = z_hi; w.v_lo[q] = v_lo; w.v_hi[q] = v_hi;
-    const int64_t i = w.list_sec[q];
-    float px, py, pz;
-    along(a, i, z, px, py, pz);
-    if (last) {
-        a.out_t[i] = z;
-        w.t_s[i] = z;
-        a.out_pts[i * 3] = px; a.out_pts[i * 3 + 1] = py; a.out_pts[i * 3 + 2] = pz;
-    } else {
-        w.pts[q * 3] = px; w.pts[q * 3 + 1] = py; w.pts[q * 3 + 2] = pz;
-    }
+    if (q >= a.w.cnt[C_NSEC]) return;
+    secant_advance_ray(a, q, last);
 }
 
 // training tail, part 1 (ray_tracing.py:71-88): rays that feed the mask loss
@@ -513,11 +495,21 @@ static int trace_forward_impl(const hm_grid_desc *desc, const hm_nffb_desc *nffb
     hipLaunchKernelGGL(sampler_reduce_kernel, dim3(g_rays), dim3(kTB), 0, st, a);
     if (cfg->n_secant_steps > 0) {
         hipLaunchKernelGGL(secant_points_kernel, dim3(g_rays), dim3(kTB), 0, st, a);
-        for (int s = 0; s < cfg->n_secant_steps; ++s) {
-            int rc = sdf(n_rays, a.w.cnt + C_NSEC);
+        // hash-grid networks with small-tile SDF launches (tile size left to the library, or 4 / 8 / 16) and a batch
+        // small enough for them: all iterations as ONE launch in which a tile of secant rays stays with its workgroup
+        // (hm_sdf.hip: trace_secant_kernel); otherwise an (SDF launch, update launch) pair per iteration
+        if (persistent_ok && !nffb && (tile_points == 0 || tile_points == 4 || tile_points == 8 || tile_points == 16) &&
+            (tile_points != 0 || n_rays <= 8192)) {
+            const int rc = hm_trace_secant_persistent(desc, mlp, table, B_fourier, frac_mode, tile_points, &a,
+                                                      cfg->n_secant_steps, stream);
             if (rc != HM_OK) return rc;
-            hipLaunchKernelGGL(secant_advance_kernel, dim3(g_rays), dim3(kTB), 0, st, a,
-                               s == cfg->n_secant_steps - 1 ? 1 : 0);
+        } else {
+            for (int s = 0; s < cfg->n_secant_steps; ++s) {
+                int rc = sdf(n_rays, a.w.cnt + C_NSEC);
+                if (rc != HM_OK) return rc;
+                hipLaunchKernelGGL(secant_advance_kernel, dim3(g_rays), dim3(kTB), 0, st, a,
+                                   s == cfg->n_secant_steps - 1 ? 1 : 0);
+            }
         }
     }
     hipLaunchKernelGGL(count_evals_kernel, dim3(1), dim3(64), 0, st, a.w.cnt, rounds + 1, cfg->n_secant_steps);

@@ -172,3 +172,31 @@ __device__ __forceinline__ void trace_advance_ray(const TraceArgs &a, int64_t i,
     w.slot_s[i] = new_ss; w.slot_e[i] = new_se;
 }
 
+__device__ __forceinline__ float secant_z(float v_lo, float v_hi, float z_lo, float z_hi) {
+    // - sdf_low * (z_high - z_low) / (sdf_high - sdf_low) + z_low, evaluated left to right
+    return __fadd_rn(__fdiv_rn(__fmul_rn(-v_lo, __fsub_rn(z_hi, z_lo)), __fsub_rn(v_hi, v_lo)), z_lo);
+}
+
+
+// one secant iteration of secant ray q (ray_tracing.py:255-266); the last one writes the refined hit
+__device__ __forceinline__ void secant_advance_ray(const TraceArgs &a, int64_t q, int last) {
+    const TraceWs &w = a.w;
+    const float v = w.vals[q];
+    if (!isfinite(v)) atomicAdd(w.cnt + C_NONFINITE, 1);
+    float z = w.z[q], z_lo = w.z_lo[q], z_hi = w.z_hi[q], v_lo = w.v_lo[q], v_hi = w.v_hi[q];
+    if (v > 0.0f) { z_lo = z; v_lo = v; }
+    if (v < 0.0f) { z_hi = z; v_hi = v; }
+    z = secant_z(v_lo, v_hi, z_lo, z_hi);
+    w.z[q] = z; w.z_lo[q] = z_lo; w.z_hi[q] = z_hi; w.v_lo[q] = v_lo; w.v_hi[q] = v_hi;
+    const int64_t i = w.list_sec[q];
+    float px, py, pz;
+    along(a, i, z, px, py, pz);
+    if (last) {
+        a.out_t[i] = z;
+        w.t_s[i] = z;
+        a.out_pts[i * 3] = px; a.out_pts[i * 3 + 1] = py; a.out_pts[i * 3 + 2] = pz;
+    } else {
+        w.pts[q * 3] = px; w.pts[q * 3 + 1] = py; w.pts[q * 3 + 2] = pz;
+    }
+}
+
