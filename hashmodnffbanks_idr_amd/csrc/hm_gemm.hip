@@ -630,7 +630,10 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K, co
     const bool buf_ok = pipe_cfg == 2 && bytesA < (1ll << 31) && bytesB < (1ll << 31);
     const bool k_whole = K % (kPipeBK * kPipeD) == 0;
     // (K >= 192: below that the rounded-up range costs more than the generic kernel's guards - K = 72 of the filter banks)
-    const bool k_tail_ok = buf_ok && ktail_cfg != 0 && (!a_kc || !b_kc) && K >= 192;
+    // (and only where the generic kernel would not split K over workgroups: a tail runs as ONE chunk, so the small
+    //  M x N weight-gradient shapes of the eager path - K = number of points - keep their split-K launch)
+    const bool k_tail_ok = buf_ok && ktail_cfg != 0 && (!a_kc || !b_kc) && K >= 192 &&
+                           (g.ep.mode != HM_EPI_NONE || t64 >= 256);
     const bool use_pipe = !big && small_cfg == 0 && !half_rows && pipe_cfg != 0 && K > 0 &&
                           (buf_ok ? (k_whole || k_tail_ok) : (k_whole && (!a_kc || g.vecA) && (!b_kc || g.vecB)));
     g.nrecA = (int32_t)(bytesA < 0x7fffffff ? bytesA : 0x7fffffff);
