@@ -801,7 +801,8 @@ def main():
                 #  has a sign change among the head samples, both passes run in full - 33.0 vs 32.5 ms at C3)
                 line["config3_leg"] = _side_leg("C3", device, False)
                 # configs[4] ("bf16"): the coarse scans with bf16 hi + lo split operands (kernel error 5e-6 against the fp32
-                # kernel; its training curve stays with the fp32 run's through steps 0 - 19, tests/test_split_gpu.py) and,
+                # kernel; its training curve stays with the fp32 run's through steps 0 - 9 in every run and through 10 - 19 in
+                # most - this network's training is chaotic -, tests/test_split_gpu.py) and,
                 # beside it, with plain bf16 operands (1.2e-3; leaves the fp32 curve after ~10 steps, tests/test_bf16_gpu.py)
                 line["config5_leg"] = _side_leg("C5", device, False, split="bf16x2")
                 line["config5_leg_plain_bf16"] = _side_leg("C5", device, True)
