@@ -1188,7 +1188,7 @@ __global__ __launch_bounds__(kThreadsSdf, 1) void sdf_fwd_small_kernel(HmLevels 
 // workgroup without stragglers (the usual case: every one) leaves at once.  The guaranteed rounds stay launches of
 // their own: there the compact list balances the live points over all CUs (a march of the whole search inside this
 // kernel was measured: -0.21 ms per step with every ray live to the end, +0.20 ms with a third of them live - the
-// slowest workgroup sets the time).  SDF values: the 16-point body's (bit-identical to hm_sdf_fwd, tile_points = 16).
+// slowest workgroup sets the time).
 // (the per-ray functions are out of line: inlined, their registers are live across the tile body)
 __device__ __attribute__((noinline)) void march_adopt_ray(const TraceArgs &a, int64_t i, int32_t *cursor, int32_t slot_base) {
     // a ray that is not done has pending points in the compact list of round `first`: move them to this workgroup's slots
@@ -1206,7 +1206,7 @@ template <int FRAC>
 __global__ __launch_bounds__(kThreadsSdf, 1) void trace_march_tail_kernel(HmLevels lv, SdfNet net,
                                                                            const float *__restrict__ table,
                                                                            const float *__restrict__ Bf, TraceArgs a,
-                                                                           int first, int rounds, int lds_floats) {
+                                                                           int first, int rounds, int lds_floats, int body16) {
     extern __shared__ __align__(16) float lds[];
     if (a.w.cnt[C_ROUND0 + first] == 0) return;     // no ray has a pending point: every state machine has finished
     int32_t *ctl = reinterpret_cast<int32_t *>(lds + lds_floats);   // [0] cursor of the round being filled
@@ -1225,7 +1225,17 @@ __global__ __launch_bounds__(kThreadsSdf, 1) void trace_march_tail_kernel(HmLeve
         if (n_loc == 0) break;      // (uniform) every ray of this workgroup is done
         // the search's evaluation count (statistics; round `first` was counted when its points were appended)
         if (tid == 0 && r > first) atomicAdd(a.w.cnt + C_ROUND0 + r, n_loc);
-        sdf_m16_body<FRAC>(lv, net, xp, n_loc, table, Bf, vp, 1, 1, lds, 0, 1 << 30);
+        // the small-tile body that fits the workgroup's OWN pending points: a straggler's rounds cost 83 instead of 130 us
+        // (600 training steps, r3aq: 7.00 ms per step with every tail round on the 16-point body against 6.43 ms with the
+        // launch-per-round form, whose compact list runs such rounds on 4-point tiles).  body16 (tile_points = 16): the
+        // 16-point body always - bit-identical to hm_sdf_fwd with 16-point tiles, how the tests compare this kernel
+        // with the generic tracer.  (With the three bodies inlined the kernel spills ~60 VGPRs, none inside an MFMA loop.)
+        if (n_loc <= 4 && !body16)
+            sdf_m8_body<FRAC, 4>(lv, net, xp, n_loc, table, Bf, vp, 1, 1, lds, 0, 1 << 30);
+        else if (n_loc <= 8 && !body16)
+            sdf_m8_body<FRAC, 8>(lv, net, xp, n_loc, table, Bf, vp, 1, 1, lds, 0, 1 << 30);
+        else
+            sdf_m16_body<FRAC>(lv, net, xp, n_loc, table, Bf, vp, 1, 1, lds, 0, 1 << 30);
         __syncthreads();            // the values (global stores of this workgroup) are visible to its threads
         if (tid == 0) ctl[0] = 0;
         __syncthreads();
@@ -1374,7 +1384,7 @@ static int sdf_net_from_desc(const HmLevels &lv, const hm_mlp_desc *mlp, int64_t
 // internal entry of the ray search (hm_trace.hip, not exported): rounds [first, rounds) of the sphere-tracing march as
 // ONE launch (trace_march_tail_kernel).  `trace_args` = a TraceArgs of hm_trace_dev.h.
 int hm_trace_march_tail(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *table, const float *B_fourier,
-                        int frac_mode, const void *trace_args, int first, int rounds, void *stream) {
+                        int frac_mode, int body16, const void *trace_args, int first, int rounds, void *stream) {
     HM_CHECK_ARG(desc && mlp && table && B_fourier && trace_args, "hm_trace_march_tail: NULL argument");
     HM_CHECK_ARG(frac_mode == HM_FRAC_REFERENCE || frac_mode == HM_FRAC_TRILINEAR, "hm_trace_march_tail: bad frac_mode");
     HM_CHECK_ARG(first >= 1 && first < 64 && rounds <= 64, "hm_trace_march_tail: bad round range");
@@ -1403,10 +1413,10 @@ int hm_trace_march_tail(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const 
     const unsigned grid = (unsigned)((a.n + 7) / 8);
     if (frac_mode == HM_FRAC_REFERENCE)
         hipLaunchKernelGGL(trace_march_tail_kernel<HM_FRAC_REFERENCE>, dim3(grid), dim3(kThreadsSdf), lds,
-                           as_stream(stream), desc->lv, net, table, B_fourier, a, first, rounds, lds_floats);
+                           as_stream(stream), desc->lv, net, table, B_fourier, a, first, rounds, lds_floats, body16);
     else
         hipLaunchKernelGGL(trace_march_tail_kernel<HM_FRAC_TRILINEAR>, dim3(grid), dim3(kThreadsSdf), lds,
-                           as_stream(stream), desc->lv, net, table, B_fourier, a, first, rounds, lds_floats);
+                           as_stream(stream), desc->lv, net, table, B_fourier, a, first, rounds, lds_floats, body16);
     HM_CHECK_LAUNCH("hm_trace_march_tail");
     return HM_OK;
 }

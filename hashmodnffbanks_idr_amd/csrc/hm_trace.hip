@@ -19,8 +19,8 @@
 
 // hm_sdf.hip (not exported): rounds [first, rounds) of the sphere-tracing march as one persistent launch
 extern "C" int hm_trace_march_tail(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *table,
-                                   const float *B_fourier, int frac_mode, const void *trace_args, int first, int rounds,
-                                   void *stream);
+                                   const float *B_fourier, int frac_mode, int body16, const void *trace_args, int first,
+                                   int rounds, void *stream);
 
 extern "C" int hm_trace_secant_persistent(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *table,
                                           const float *B_fourier, int frac_mode, int tile_points, const void *trace_args,
@@ -488,7 +488,8 @@ static int trace_forward_impl(const hm_grid_desc *desc, const hm_nffb_desc *nffb
         hipLaunchKernelGGL(trace_advance_kernel, dim3(g_rays), dim3(kTB), 0, st, a, r + 1 < 64 ? r + 1 : 63);
     }
     if (tail) {
-        const int rc = hm_trace_march_tail(desc, mlp, table, B_fourier, frac_mode, &a, launched, rounds, stream);
+        const int rc = hm_trace_march_tail(desc, mlp, table, B_fourier, frac_mode, tile_points == 16 ? 1 : 0, &a, launched,
+                                           rounds, stream);
         if (rc != HM_OK) return rc;
     }
     hipLaunchKernelGGL(trace_finalize_kernel, dim3(g_rays), dim3(kTB), 0, st, a);
