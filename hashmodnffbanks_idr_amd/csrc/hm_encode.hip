@@ -601,6 +601,50 @@ __global__ __launch_bounds__(kThreads) void encode_bwd_table_kernel(HmLevels lv,
     for (int f = 0; f < F; ++f) atomicAdd(row + f, __fmul_rn(w, g[f]));
 }
 
+// The same scatter for SMALL tables (all levels together <= 4096 rows: the view-direction grid of the rendering network
+// has 8 rows per level): every point of a batch lands on the same few rows, and 2048 points x 4 levels of global float
+// atomics on 32 rows serialise in the L2 (45 us for that call, as much as the two 49 k-lane scatters into the 2^19-row
+// table together).  Each workgroup sums its share in an LDS copy of the whole table (LDS float atomics) and adds the
+// rows it touched to d_table once.
+constexpr int kSmallTableRows = 4096;
+template <int FRAC>
+__global__ __launch_bounds__(kThreads) void encode_bwd_table_small_kernel(HmLevels lv, const float *__restrict__ x,
+                                                                          int64_t n, const float *__restrict__ d_feat,
+                                                                          int64_t d_feat_stride,
+                                                                          float *__restrict__ d_table, int total_rows) {
+    extern __shared__ __align__(16) float acc_lds[];      // [total_rows * F]
+    constexpr int C = FRAC == HM_FRAC_REFERENCE ? 1 : 8;
+    const int L = lv.L, F = lv.F;
+    const int cells = total_rows * F;
+    for (int k = threadIdx.x; k < cells; k += kThreads) acc_lds[k] = 0.0f;
+    __syncthreads();
+    const int64_t total = n * L * C;
+    for (int64_t gid = (int64_t)blockIdx.x * kThreads + threadIdx.x; gid < total; gid += (int64_t)gridDim.x * kThreads) {
+        const int c = (int)(gid % C);
+        const int64_t pl = gid / C;
+        const int64_t i = pl / L;
+        const int l = (int)(pl - i * L);
+        uint32_t u[3];
+        float w = 1.0f;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            float wd;
+            voxel_and_weight<FRAC>(x[i * 3 + d], lv.res[l], (c >> d) & 1, u[d], wd);
+            w = __fmul_rn(w, wd);
+        }
+        if (w == 0.0f) continue;
+        const uint32_t id = hm_mod_rows(hm_hash3(u[0], u[1], u[2]), lv.rows[l], lv.magic[l]);
+        const float *g = d_feat + i * d_feat_stride + l * F;
+        float *row = acc_lds + ((size_t)lv.row_off[l] + id) * F;
+        for (int f = 0; f < F; ++f) atomicAdd(row + f, __fmul_rn(w, g[f]));
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < cells; k += kThreads) {
+        const float v = acc_lds[k];
+        if (v != 0.0f) atomicAdd(d_table + k, v);
+    }
+}
+
 // The same scatter for data-parallel steps (parallel.TouchedRowExchange): besides adding into d_table it lists every
 // table row it touches ONCE - a bit per row is claimed with atomicOr, the lanes of a wave that claimed a new row take
 // consecutive slots of touched_rows with one atomicAdd per wave.  The rank's (row, value) pairs are then read off
@@ -1146,6 +1190,19 @@ int hm_encode_bwd_table(const hm_grid_desc *desc, const float *x, int64_t n, con
     const int64_t threads = n * lv.L * (frac_mode == HM_FRAC_REFERENCE ? 1 : 8);
     const int64_t grid = (threads + kThreads - 1) / kThreads;
     HM_CHECK_ARG(grid <= 0x7fffffffLL, "hm_encode_bwd_table: n too large for one launch");
+    if (desc->total_rows <= (uint64_t)kSmallTableRows && (int64_t)desc->total_rows * lv.F * 4 <= 48 * 1024 && threads >= 4096) {
+        // small table, many contributions: LDS-privatised sums, at most 64 workgroups
+        const unsigned g_small = (unsigned)(grid < 64 ? grid : 64);
+        const size_t lds = sizeof(float) * (size_t)desc->total_rows * lv.F;
+        if (frac_mode == HM_FRAC_REFERENCE)
+            hipLaunchKernelGGL(encode_bwd_table_small_kernel<HM_FRAC_REFERENCE>, dim3(g_small), dim3(kThreads), lds,
+                               as_stream(stream), lv, x, n, d_feat, d_feat_stride, d_table, (int)desc->total_rows);
+        else
+            hipLaunchKernelGGL(encode_bwd_table_small_kernel<HM_FRAC_TRILINEAR>, dim3(g_small), dim3(kThreads), lds,
+                               as_stream(stream), lv, x, n, d_feat, d_feat_stride, d_table, (int)desc->total_rows);
+        HM_CHECK_LAUNCH("hm_encode_bwd_table");
+        return HM_OK;
+    }
     if (frac_mode == HM_FRAC_REFERENCE)
         hipLaunchKernelGGL(encode_bwd_table_kernel<HM_FRAC_REFERENCE>, dim3((unsigned)grid), dim3(kThreads), 0,
                            as_stream(stream), lv, x, n, d_feat, d_feat_stride, d_table);

@@ -414,3 +414,36 @@ def test_own_radix_sort_equals_stable_sort(n, bits):
     assert torch.equal(sk, rk)
     assert torch.equal(perm, rp)
     assert ops.sort_pairs(keys[:0], bits)[0].numel() == 0
+
+
+@pytest.mark.parametrize("cfg", ["viewdir", "tiny"])
+@pytest.mark.parametrize("mode", ["reference", "trilinear"])
+def test_encode_bwd_table_small_table_path(cfg, mode):
+    """tables of <= 4096 rows with many contributions take the LDS-privatised scatter (encode_bwd_table_small_kernel:
+    the view-direction grid of the rendering network has 8 rows per level, 2048 rays land on them): against the C
+    oracle's scatter and - adjoint identity - against the forward gather, in both weight modes, accumulating into a
+    non-zero tensor."""
+    from hashmodnffbanks_idr_amd import ops
+    emb, table, B = _embedder(cfg, 5, 0.5, frac_mode=mode)
+    B = torch.from_numpy(B).cuda()
+    L, T, b, d = P.CONFIGS[cfg]
+    assert emb.desc.total_rows <= 4096
+    fm = ops.FRAC_MODES[mode]
+    n = 3001
+    g = torch.Generator(device="cpu").manual_seed(21)
+    x = (torch.rand((n, 3), generator=g) * 2.2 - 1.1)
+    d_feat = torch.randn((n, L * 2), generator=g)
+    got = ops.encode_bwd_table(emb.desc, x.cuda(), d_feat.cuda(), fm)
+    d_out = np.zeros((n, 3 + 2 * L + 2 * L), np.float32)
+    d_out[:, 3 + 2 * L:] = d_feat.numpy()
+    ref = O.encode_bwd_table(O.Grid(L, T, b, d), x.numpy(), d_out, fm)
+    scale = np.abs(ref).max()
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=0, atol=2e-6 * scale)
+    feats = ops.encode_fwd(emb.desc, x.cuda(), emb.table.detach(), B, fm, hash_only=True)
+    lhs = (feats.double() * d_feat.cuda().double()).sum().item()
+    rhs = (emb.table.detach().double() * got.double()).sum().item()
+    mag = (feats.double().abs() * d_feat.cuda().double().abs()).sum().item()     # (the sum cancels: ~3000 fp32 terms per row)
+    assert abs(lhs - rhs) <= 1e-6 * mag, (lhs, rhs, mag)
+    acc = torch.full_like(got, 0.25)
+    ops.encode_bwd_table(emb.desc, x.cuda(), d_feat.cuda(), fm, out=acc)
+    np.testing.assert_allclose((acc - 0.25).cpu().numpy(), ref, rtol=0, atol=4e-6 * scale)
