@@ -70,6 +70,7 @@ SIGNATURES = {
     "hm_colsum_acc": (_int, [_p, _i64, _i64, _i64, _p, _p]),
     "hm_colsum_acc_multi": (_int, [_p, _int, _p]),
     "hm_copy2d_f32": (_int, [_p, _i64, _p, _i64, _i64, _i64, _p]),
+    "hm_camera_rays": (_int, [_p, _p, _p, _i64, _i64, C.c_float, _p, _p, _p, _p, _p]),
     "hm_idr_loss": (_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, C.c_float, C.c_float, C.c_float, _p, _p, _p, _p, _p]),
     "hm_adam_scratch_floats": (_i64, [_p, _int]),
     "hm_adam_step": (_int, [_p, _int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _p, _p]),

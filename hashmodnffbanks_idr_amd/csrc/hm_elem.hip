@@ -566,4 +566,77 @@ int hm_colsum_acc_multi(const hm_colsum_item *items, int n_items, void *stream) 
     return HM_OK;
 }
 
+
+}  // extern "C"
+
+namespace {
+// Camera rays and their bounding-sphere intersections in ONE launch (fixed cameras of the static training step):
+// rend_util.get_camera_params (rend_util.py:48-75: lift -> pose x pixel -> normalise) and rend_util.get_sphere_intersection
+// (:141-162) are ~38 elementwise / reduction / 4x4-bmm launches over a few thousand rays in torch.  The arithmetic follows
+// the reference expressions term by term (separate roundings; the K = 4 / K = 3 products of the two bmm calls and the
+// squared norms as k-ordered fma chains).
+__global__ __launch_bounds__(256) void camera_rays_kernel(const float *__restrict__ uv, const float *__restrict__ pose,
+                                                          const float *__restrict__ intr, int64_t n_img, int64_t n_pix,
+                                                          float r2, float *__restrict__ dirs, float *__restrict__ cam,
+                                                          float *__restrict__ t_sphere, uint8_t *__restrict__ hit) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_img * n_pix) return;
+    const int64_t b = i / n_pix;
+    const float *P = pose + b * 16, *K = intr + b * 16;
+    const float fx = K[0], sk = K[1], cx = K[2], fy = K[5], cy = K[6];
+    const float x = uv[i * 2], y = uv[i * 2 + 1];
+    // lift (z = 1): (x - cx + cy * sk / fy - sk * y / fy) / fx * z ;  (y - cy) / fy * z
+    float xl = __fsub_rn(x, cx);
+    xl = __fadd_rn(xl, __fdiv_rn(__fmul_rn(cy, sk), fy));
+    xl = __fsub_rn(xl, __fdiv_rn(__fmul_rn(sk, y), fy));
+    xl = __fmul_rn(__fdiv_rn(xl, fx), 1.0f);
+    const float yl = __fmul_rn(__fdiv_rn(__fsub_rn(y, cy), fy), 1.0f);
+    float d[3], c[3];
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) {
+        float w = __fmul_rn(P[rr * 4], xl);
+        w = __fmaf_rn(P[rr * 4 + 1], yl, w);
+        w = __fmaf_rn(P[rr * 4 + 2], 1.0f, w);
+        w = __fmaf_rn(P[rr * 4 + 3], 1.0f, w);
+        c[rr] = P[rr * 4 + 3];
+        d[rr] = __fsub_rn(w, c[rr]);
+    }
+    const float nrm = __fsqrt_rn(__fmaf_rn(d[2], d[2], __fmaf_rn(d[1], d[1], __fmul_rn(d[0], d[0]))));
+    const float den = fmaxf(nrm, 1e-12f);
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) {
+        d[rr] = __fdiv_rn(d[rr], den);
+        dirs[i * 3 + rr] = d[rr];
+    }
+    if (i - b * n_pix == 0) { cam[b * 3] = c[0]; cam[b * 3 + 1] = c[1]; cam[b * 3 + 2] = c[2]; }
+    // sphere: dot = <d, c>;  under = dot^2 - (|c|^2 - r^2)
+    const float dot = __fmaf_rn(d[2], c[2], __fmaf_rn(d[1], c[1], __fmul_rn(d[0], c[0])));
+    const float cn = __fsqrt_rn(__fmaf_rn(c[2], c[2], __fmaf_rn(c[1], c[1], __fmul_rn(c[0], c[0]))));
+    const float under = __fsub_rn(__fmul_rn(dot, dot), __fsub_rn(__fmul_rn(cn, cn), r2));
+    const bool m = under > 0.0f;
+    const float root = __fsqrt_rn(m ? under : 1.0f);
+    float t0 = __fsub_rn(__fmul_rn(root, -1.0f), dot), t1 = __fsub_rn(root, dot);
+    t0 = m ? t0 : 0.0f; t1 = m ? t1 : 0.0f;
+    t_sphere[i * 2] = fmaxf(t0, 0.0f);
+    t_sphere[i * 2 + 1] = fmaxf(t1, 0.0f);
+    hit[i] = m ? 1 : 0;
+}
+}  // namespace
+
+extern "C" {
+
+int hm_camera_rays(const float *uv, const float *pose, const float *intrinsics, int64_t n_images, int64_t n_pixels,
+                   float radius, float *ray_dirs, float *cam_loc, float *t_sphere, uint8_t *hit, void *stream) {
+    HM_CHECK_ARG(n_images >= 0 && n_pixels >= 0, "hm_camera_rays: bad size");
+    if (n_images * n_pixels == 0) return HM_OK;
+    HM_CHECK_ARG(uv && pose && intrinsics && ray_dirs && cam_loc && t_sphere && hit, "hm_camera_rays: NULL pointer");
+    const int64_t n = n_images * n_pixels;
+    const double r2 = (double)radius * (double)radius;          // (python: r ** 2 in double, then a float32 scalar)
+    hipLaunchKernelGGL(camera_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), uv, pose, intrinsics, n_images, n_pixels, (float)r2, ray_dirs,
+                       cam_loc, t_sphere, hit);
+    HM_CHECK_LAUNCH("hm_camera_rays");
+    return HM_OK;
+}
+
 }  // extern "C"

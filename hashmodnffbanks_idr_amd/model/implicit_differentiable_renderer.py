@@ -358,6 +358,10 @@ class IDRNetwork(nn.Module):
         # forward_static: the second SDF evaluation of the ray points reuses the first one's MLP forward (same inputs in
         # value); False re-evaluates them (A/B, tests)
         self.reuse_ray_rows = True
+        # forward_static: camera rays + sphere intersections from one kernel (ops.camera_rays); False / HM_FUSED_CAMERA=0:
+        # the torch expressions of utils/rend_util.py
+        import os
+        self.fused_camera = os.environ.get("HM_FUSED_CAMERA", "1") != "0"
 
     def forward(self, input):
         cache = {}
@@ -475,21 +479,30 @@ class IDRNetwork(nn.Module):
             _fold_all((self.implicit_network, self.rendering_network), cache)
             uv, pose, intrinsics = input["uv"], input["pose"], input["intrinsics"]
             object_mask = input["object_mask"].reshape(-1)
-            ray_dirs, cam_loc = rend_util.get_camera_params(uv, pose, intrinsics)
+            if pose.requires_grad:
+                raise RuntimeError("forward_static needs fixed cameras (pose without gradient)")
+            sphere = None
+            if self.fused_camera and uv.is_cuda and pose.dim() == 3 and tuple(pose.shape[1:]) == (4, 4):
+                # rays and their bounding-sphere intersections in ONE launch (ops.camera_rays) instead of the ~38
+                # elementwise / bmm launches of rend_util.get_camera_params + get_sphere_intersection
+                ray_dirs, cam_loc, t_sph, hit = ops.camera_rays(uv, pose, intrinsics, self.ray_tracer.object_bounding_sphere)
+                sphere = (t_sph, hit)
+            else:
+                ray_dirs, cam_loc = rend_util.get_camera_params(uv, pose, intrinsics)
             if ray_dirs.requires_grad or cam_loc.requires_grad:
                 raise RuntimeError("forward_static needs fixed cameras (pose without gradient)")
             batch_size, num_pixels, _ = ray_dirs.shape
             n_rays = batch_size * num_pixels
             self.implicit_network.eval()
-            old = self.ray_tracer.steps_override
-            self.ray_tracer.steps_override = steps_u
+            old = (self.ray_tracer.steps_override, self.ray_tracer.sphere_override)
+            self.ray_tracer.steps_override, self.ray_tracer.sphere_override = steps_u, sphere
             try:
                 with torch.no_grad():
                     _, network_object_mask, dists = self.ray_tracer(
                         sdf=self.implicit_network.sdf, cam_loc=cam_loc, object_mask=object_mask,
                         ray_directions=ray_dirs)
             finally:
-                self.ray_tracer.steps_override = old
+                self.ray_tracer.steps_override, self.ray_tracer.sphere_override = old
             self.implicit_network.train()
             points = (cam_loc.unsqueeze(1) + dists.reshape(batch_size, num_pixels, 1) * ray_dirs).reshape(-1, 3)
             ray_dirs = ray_dirs.reshape(-1, 3)

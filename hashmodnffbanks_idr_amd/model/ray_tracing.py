@@ -35,6 +35,7 @@ class RayTracing(nn.Module):
         self.n_secant_steps = n_secant_steps
         self.verbose = False      # the reference prints three lines per call (:61-64), each a device sync
         self.steps_override = None  # optional [n_steps] tensor replacing the U(0,1) draw of step 3
+        self.sphere_override = None  # optional (t_sphere [B,N,2], hit [B,N]) the caller already has (ops.camera_rays)
         self.use_device_tracer = True   # sync-free HIP state-machine tracer when `sdf` is the package's network
         # device tracer: the sampler's first pass evaluates samples 0..sampler_head-1 (and the last one), the second
         # pass the remaining samples of the rays whose first sign change is not among them - the reference reads
@@ -69,8 +70,11 @@ class RayTracing(nn.Module):
         N = B * P
         dev = ray_directions.device
         with torch.no_grad():
-            t_sphere, hit = rend_util.get_sphere_intersection(cam_loc.detach(), ray_directions.detach(),
-                                                              r=self.object_bounding_sphere)
+            if self.sphere_override is not None:
+                t_sphere, hit = self.sphere_override
+            else:
+                t_sphere, hit = rend_util.get_sphere_intersection(cam_loc.detach(), ray_directions.detach(),
+                                                                  r=self.object_bounding_sphere)
             cfg = _lib.TraceCfg(float(self.object_bounding_sphere), float(self.sdf_threshold),
                                 float(self.line_search_step), int(self.line_step_iters),
                                 int(self.sphere_tracing_iters), int(self.n_steps), int(self.n_secant_steps),

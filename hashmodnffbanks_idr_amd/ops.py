@@ -773,6 +773,24 @@ def trace_workspace_bytes(n_rays, cfg, nffb_levels=0):
     return check(lib().hm_trace_workspace_bytes(int(n_rays), C.byref(cfg)))
 
 
+def camera_rays(uv, pose, intrinsics, radius):
+    """(ray_dirs [B,N,3], cam_loc [B,3], t_sphere [B,N,2], hit [B,N] bool) of fixed 4x4 cameras in one launch
+    (hm_camera_rays: rend_util.get_camera_params + get_sphere_intersection; no gradient)."""
+    require_gpu(uv, pose, intrinsics)
+    Bn, N = int(uv.shape[0]), int(uv.shape[1])
+    if tuple(pose.shape[1:]) != (4, 4) or tuple(intrinsics.shape[1:]) != (4, 4):
+        raise ValueError("hashmod camera_rays: pose and intrinsics must be [B,4,4]")
+    uv_c, pose_c, k_c = uv.detach().float().contiguous(), pose.detach().float().contiguous(), intrinsics.detach().float().contiguous()
+    dev = uv.device
+    dirs = torch.empty((Bn, N, 3), dtype=torch.float32, device=dev)
+    cam = torch.empty((Bn, 3), dtype=torch.float32, device=dev)
+    t = torch.empty((Bn, N, 2), dtype=torch.float32, device=dev)
+    hit = torch.empty((Bn, N), dtype=torch.uint8, device=dev)
+    check(lib().hm_camera_rays(dptr(uv_c), dptr(pose_c), dptr(k_c), Bn, N, float(radius), dptr(dirs), dptr(cam), dptr(t),
+                               dptr(hit), stream_ptr(uv_c)))
+    return dirs, cam, t, hit.bool()
+
+
 def trace_forward(desc, packed, table, B, frac_mode, tile_points, cfg, cam_loc, ray_dirs, object_mask, t_sphere,
                   hit_mask, rays_per_image, sampler_fracs, steps_u, workspace, stats=None, nffb=None):
     """Enqueues the whole intersection search (no host sync).  Returns (points, net_mask_u8, dists).

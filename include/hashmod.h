@@ -509,6 +509,14 @@ HM_API int hm_idr_loss(const float *rgb, const float *rgb_gt, const float *sdf, 
                        float eikonal_weight, float mask_weight, float alpha, float *terms, float *d_rgb, float *d_sdf,
                        float *d_grad, void *stream);
 
+/* ---- camera rays + bounding-sphere intersections --------------------------------------------------
+ * Replaces rend_util.get_camera_params for 4x4 poses (utils/rend_util.py:48-75: lift, pose x pixel, normalise) and
+ * rend_util.get_sphere_intersection (:141-162) for the rays it produces, as one launch: uv [B,N,2], pose / intrinsics
+ * [B,4,4] -> ray_dirs [B,N,3], cam_loc [B,3], t_sphere [B,N,2] (clamped at 0), hit [B,N] (bytes).  Fixed cameras only:
+ * nothing here is differentiated.                                                                        */
+HM_API int hm_camera_rays(const float *uv, const float *pose, const float *intrinsics, int64_t n_images, int64_t n_pixels,
+                          float radius, float *ray_dirs, float *cam_loc, float *t_sphere, uint8_t *hit, void *stream);
+
 /* ---- optimizer tail of the training iteration ---------------------------------------------------
  * torch.nn.utils.clip_grad_norm_(parameters, max_norm) followed by torch.optim.Adam.step()
  * (training/idr_train.py:128,306-309; amsgrad / weight decay off as in the reference) over all tensors in

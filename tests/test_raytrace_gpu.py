@@ -240,3 +240,41 @@ def test_lazy_sampler_equals_single_pass(golden, tag, n_rays, mode):
           + ", ".join(f"head {h}: {r[1]['sdf_evals']}" for h, r in res.items()))
     if tag == "C2":      # near the geometric initialisation the first sign change comes early
         assert res[16][1]["sdf_evals"] < 0.9 * st0["sdf_evals"]
+
+
+def test_camera_rays_kernel_matches_rend_util(golden):
+    """ops.camera_rays (hm_camera_rays: ONE launch) against rend_util.get_camera_params + get_sphere_intersection (the
+    reference's expressions on torch ops, ~38 launches) on the cameras of the reference fixture and on random ones:
+    directions and camera centres to an ulp or two, hit masks equal away from the sphere's silhouette, t to 1e-6."""
+    from hashmodnffbanks_idr_amd import ops
+    from hashmodnffbanks_idr_amd.utils import rend_util
+    g = golden("camera")
+    cases = [(torch.from_numpy(g["uv"]).cuda(), torch.from_numpy(g["pose44"]).cuda(), torch.from_numpy(g["K"]).cuda())]
+    gen = torch.Generator(device="cpu").manual_seed(4)
+    for Bn, N in ((1, 2048), (3, 777)):
+        uv = (torch.rand((Bn, N, 2), generator=gen) * torch.tensor([1600.0, 1200.0])).cuda()
+        K = torch.eye(4).repeat(Bn, 1, 1)
+        K[:, 0, 0] = 2800 + 100 * torch.rand(Bn, generator=gen); K[:, 1, 1] = 2850.0; K[:, 0, 2] = 810.0; K[:, 1, 2] = 590.0
+        K[:, 0, 1] = 0.3
+        centre = torch.nn.functional.normalize(torch.randn((Bn, 3), generator=gen), dim=1) * 4.5
+        z = torch.nn.functional.normalize(-centre + 0.05 * torch.randn((Bn, 3), generator=gen), dim=1)   # looks at the object
+        xax = torch.nn.functional.normalize(torch.linalg.cross(z, torch.randn((Bn, 3), generator=gen)), dim=1)
+        P4 = torch.eye(4).repeat(Bn, 1, 1)
+        P4[:, :3, 0], P4[:, :3, 1], P4[:, :3, 2], P4[:, :3, 3] = xax, torch.linalg.cross(z, xax), z, centre
+        cases.append((uv, P4.cuda(), K.cuda()))
+    for ci, (uv, pose, K) in enumerate(cases):
+        d_ref, c_ref = rend_util.get_camera_params(uv, pose, K)
+        t_ref, h_ref = rend_util.get_sphere_intersection(c_ref, d_ref, r=1.0)
+        d, c, t, h = ops.camera_rays(uv, pose, K, 1.0)
+        assert torch.equal(c, c_ref)
+        dd = (d - d_ref).abs().max().item()
+        same = float((d == d_ref).float().mean())
+        print(f"camera_rays: max |d dir| {dd:.2e} ({100 * same:.1f} % of the components bit-equal), "
+              f"max |d t| {(t - t_ref).abs().max().item():.2e}, hit flips {int((h != h_ref).sum())} of {h.numel()}")
+        assert dd <= 2.5e-7
+        assert int((h != h_ref).sum()) <= max(1, h.numel() // 1000)
+        ok = h & h_ref
+        assert ci == 0 or 0.05 * h.numel() < int(ok.sum()) < h.numel()      # the image holds the sphere's silhouette
+        inner = ok & ((t_ref[..., 1] - t_ref[..., 0]) > 0.2)               # sqrt() amplifies an ulp of <d, c> at the silhouette
+        assert (t - t_ref)[inner].abs().max().item() <= 5e-5           # (|c| = 4.5: an ulp of d moves dot^2 by 4e-6, root 0.1)
+        assert (t - t_ref)[ok].abs().max().item() <= 5e-3
