@@ -65,17 +65,15 @@ constexpr int kThreadsSdf = 512;
 constexpr int kWaves = 8;
 constexpr int kGroupFloats = kPts * 4;  // floats per k-group row of X: [point][4]
 
-template <int FRAC>
-__global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_kernel(HmLevels lv, SdfNet net,
-                                                                  const float *__restrict__ x, int64_t n,
-                                                                  const float *__restrict__ table,
-                                                                  const float *__restrict__ Bf,
-                                                                  float *__restrict__ out, int64_t out_stride,
-                                                                  int out_cols, const int32_t *__restrict__ n_dev, int64_t run_min,
-                                                                  int64_t run_max) {
-    extern __shared__ __align__(16) float lds[];
-    if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));  // device-side point count (sync-free callers)
-    if (n < run_min || n > run_max) return;          // the other tile-size kernel owns this batch size
+// The 64-point tile loop of sdf_fwd_kernel / sdf_scan_secant_kernel.  DYN = false: the static schedule below
+// (tile = round * grid + workgroup); DYN = true: the SAME tiles in the same enumeration, handed out by an atomic cursor
+// (zero at launch) - workgroups that start late (they carried secant rays first) simply take fewer of them.
+template <int FRAC, bool DYN>
+__device__ __forceinline__ void sdf64_run(const HmLevels &lv, const SdfNet &net, const float *__restrict__ x, int64_t n,
+                                          const float *__restrict__ table, const float *__restrict__ Bf,
+                                          float *__restrict__ out, int64_t out_stride, int out_cols, float *lds,
+                                          unsigned *cursor) {
+    __shared__ unsigned s_next_tile;
     float *X = lds;
     float *EMB = lds + (size_t)net.x_groups * kGroupFloats;
     float *SX = EMB + (size_t)net.emb_groups * kGroupFloats;  // [64][3] raw points
@@ -98,14 +96,24 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_kernel(HmLevels lv, Sd
     const int64_t rem_base = rounds * G * kPts;
     const int64_t rem_step = (n - rem_base <= G * 32) ? 32 : kPts;
 
-    for (int64_t it = 0; it <= rounds; ++it) {
+    for (int64_t it = 0;; ++it) {
+        int64_t itr = it, wg = blockIdx.x;
+        if (DYN) {
+            __syncthreads();   // every thread has read the previous hand-out
+            if (tid == 0) s_next_tile = atomicAdd(cursor, 1u);
+            __syncthreads();
+            const int64_t u = s_next_tile;
+            itr = u / G;
+            wg = u - itr * G;
+        }
+        if (itr > rounds) break;
         int64_t base;
         int cnt;
-        if (it < rounds) {
-            base = (it * G + blockIdx.x) * kPts;
+        if (itr < rounds) {
+            base = (itr * G + wg) * kPts;
             cnt = kPts;
         } else {
-            base = rem_base + (int64_t)blockIdx.x * rem_step;
+            base = rem_base + wg * rem_step;
             if (base >= n) break;
             cnt = (int)min(rem_step, n - base);
         }
@@ -386,6 +394,20 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_kernel(HmLevels lv, Sd
             }
         }
     }
+}
+
+template <int FRAC>
+__global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_kernel(HmLevels lv, SdfNet net,
+                                                                  const float *__restrict__ x, int64_t n,
+                                                                  const float *__restrict__ table,
+                                                                  const float *__restrict__ Bf,
+                                                                  float *__restrict__ out, int64_t out_stride,
+                                                                  int out_cols, const int32_t *__restrict__ n_dev, int64_t run_min,
+                                                                  int64_t run_max) {
+    extern __shared__ __align__(16) float lds[];
+    if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));  // device-side point count (sync-free callers)
+    if (n < run_min || n > run_max) return;          // the other tile-size kernel owns this batch size
+    sdf64_run<FRAC, false>(lv, net, x, n, table, Bf, out, out_stride, out_cols, lds, nullptr);
 }
 
 
@@ -1271,14 +1293,9 @@ __device__ __attribute__((noinline)) void secant_step_ray(const TraceArgs &a, in
 }
 
 template <int FRAC>
-__global__ __launch_bounds__(kThreadsSdf, 1) void trace_secant_kernel(HmLevels lv, SdfNet net,
-                                                                       const float *__restrict__ table,
-                                                                       const float *__restrict__ Bf, TraceArgs a,
-                                                                       int n_iters, int64_t m8_max, int64_t m4_max) {
-    extern __shared__ __align__(16) float lds[];
-    const int64_t n = a.w.cnt[C_NSEC];
-    if (n <= 0) return;
-    const int pts = n <= m4_max ? 4 : (n <= m8_max ? 8 : 16);
+__device__ __forceinline__ void secant_role(const HmLevels &lv, const SdfNet &net, const float *__restrict__ table,
+                                            const float *__restrict__ Bf, const TraceArgs &a, int n_iters, int64_t n,
+                                            int pts, float *lds) {
     const int64_t n_tiles = (n + pts - 1) / pts;
     for (int it = 0; it < n_iters; ++it) {
         if (pts == 4)
@@ -1294,6 +1311,47 @@ __global__ __launch_bounds__(kThreadsSdf, 1) void trace_secant_kernel(HmLevels l
         }
         __syncthreads();       // the next iteration's points are written
     }
+}
+
+template <int FRAC>
+__global__ __launch_bounds__(kThreadsSdf, 1) void trace_secant_kernel(HmLevels lv, SdfNet net,
+                                                                       const float *__restrict__ table,
+                                                                       const float *__restrict__ Bf, TraceArgs a,
+                                                                       int n_iters, int64_t m8_max, int64_t m4_max) {
+    extern __shared__ __align__(16) float lds[];
+    const int64_t n = a.w.cnt[C_NSEC];
+    if (n <= 0) return;
+    const int pts = n <= m4_max ? 4 : (n <= m8_max ? 8 : 16);
+    secant_role<FRAC>(lv, net, table, Bf, a, n_iters, n, pts, lds);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Closest-approach scan + secant refinement in ONE launch (training, tile size left to the library).  The secant
+// iterations are a chain of eight dependent small-tile evaluations that keeps a few dozen workgroups busy for most of a
+// millisecond while the rest of the chip idles; the closest-approach scan of the mask-loss rays (ray_tracing.py:71-92,
+// ~77 k points at the bench workload) depends on neither the sampler nor the secant.  Here the workgroups that own secant
+// tiles run that chain first (trace_secant_kernel's code), every other workgroup starts on the scan's 64-point tiles at
+// once, and the tiles are handed out by an atomic cursor, so the late workgroups simply take fewer.  Values: the scan's
+// are those of sdf_fwd_kernel (same tiles); the secant uses 16-point tiles when the scan is long enough to hide their
+// latency (a 16-point tile does four times the rays of a 4-point one for 1.6x the time: least chip time), and the list
+// length rule of trace_secant_kernel otherwise.
+template <int FRAC>
+__global__ __launch_bounds__(kThreadsSdf, 2) void sdf_scan_secant_kernel(HmLevels lv, SdfNet net,
+                                                                          const float *__restrict__ table,
+                                                                          const float *__restrict__ Bf, TraceArgs a,
+                                                                          int n_iters, int64_t m8_max, int64_t m4_max,
+                                                                          int64_t scan_off, int64_t scan_min,
+                                                                          int64_t scan_hide) {
+    extern __shared__ __align__(16) float lds[];
+    const int64_t n_scan = max(a.w.cnt[C_NSEL_PTS], 0);
+    const int64_t n_sec = a.w.cnt[C_NSEC];
+    if (n_sec > 0 && n_iters > 0) {
+        const int pts = n_scan >= scan_hide ? 16 : (n_sec <= m4_max ? 4 : (n_sec <= m8_max ? 8 : 16));
+        secant_role<FRAC>(lv, net, table, Bf, a, n_iters, n_sec, pts, lds);
+    }
+    if (n_scan < scan_min) return;        // (a short scan is the small-tile launch's job)
+    sdf64_run<FRAC, true>(lv, net, a.w.pts + scan_off * 3, n_scan, table, Bf, a.w.vals + scan_off, 1, 1, lds,
+                          reinterpret_cast<unsigned *>(a.w.cnt + C_TILE_CURSOR));
 }
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
@@ -1468,6 +1526,56 @@ int hm_trace_secant_persistent(const hm_grid_desc *desc, const hm_mlp_desc *mlp,
         hipLaunchKernelGGL(trace_secant_kernel<HM_FRAC_TRILINEAR>, dim3(grid), dim3(kThreadsSdf), lds, as_stream(stream),
                            desc->lv, net, table, B_fourier, a, n_iters, m8_max, m4_max);
     HM_CHECK_LAUNCH("hm_trace_secant_persistent");
+    return HM_OK;
+}
+
+// Closest-approach scan (points at pts + scan_off, count cnt[C_NSEL_PTS]) and the secant refinement in one launch
+// (sdf_scan_secant_kernel); scans of <= 8192 points run on the small-tile launch in front of it.  tile_points = 0 only.
+int hm_trace_scan_secant(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *table, const float *B_fourier,
+                         int frac_mode, const void *trace_args, int n_iters, int64_t scan_off, int64_t scan_capacity,
+                         void *stream) {
+    HM_CHECK_ARG(desc && mlp && table && B_fourier && trace_args, "hm_trace_scan_secant: NULL argument");
+    HM_CHECK_ARG(frac_mode == HM_FRAC_REFERENCE || frac_mode == HM_FRAC_TRILINEAR, "hm_trace_scan_secant: bad frac_mode");
+    const TraceArgs &a = *static_cast<const TraceArgs *>(trace_args);
+    SdfNet net;
+    bool have16 = false;
+    int rc = sdf_net_from_desc(desc->lv, mlp, 0, net, have16);
+    if (rc != HM_OK) return rc;
+    HM_CHECK_ARG(have16, "hm_trace_scan_secant: needs w_packed_m16 in every layer");
+    if (a.n == 0) return HM_OK;
+    constexpr int64_t kSmall = 8192;
+    // the scan's small-count form (tile_points -1: returns at once above kSmall live points)
+    rc = hm_sdf_fwd(desc, mlp, a.w.pts + scan_off * 3, scan_capacity, table, B_fourier, a.w.vals + scan_off, 1, 1, frac_mode,
+                    -1, a.w.cnt + C_NSEL_PTS, 0, stream);
+    if (rc != HM_OK) return rc;
+    const int emb_b16 = (desc->lv.E + 15) / 16;
+    const size_t lds16 = sizeof(float) * ((size_t)(2 * net.x_groups + emb_b16 * 4) * kGroupFloats16 + kPts16 * 4 +
+                                          kWaves * kPts16);
+    const size_t lds64 = sizeof(float) * ((size_t)(net.x_groups + net.emb_groups) * kGroupFloats + kPts * 4 + kWaves * kPts);
+    HM_CHECK_ARG(lds16 <= 96 * 1024 && lds64 <= 160 * 1024 - 64, "hm_trace_scan_secant: network does not fit the LDS tiles");
+    const size_t lds = lds16 > lds64 ? lds16 : lds64;
+    static thread_local bool attr_done = false;
+    if (!attr_done) {  // opt in to >64 KB dynamic LDS once (not a stream operation)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sdf_scan_secant_kernel<HM_FRAC_REFERENCE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(sdf_scan_secant_kernel<HM_FRAC_TRILINEAR>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+        if (e != hipSuccess) return hm_fail(HM_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+        attr_done = true;
+    }
+    // 16-point secant tiles once the scan keeps the chip busy for longer than their chain takes (8 x 131 us ~ 2.3 rounds
+    // of 64-point tiles: 3 rounds = 49 152 points)
+    const int64_t scan_hide = 3 * 256 * kPts;
+    if (frac_mode == HM_FRAC_REFERENCE)
+        hipLaunchKernelGGL(sdf_scan_secant_kernel<HM_FRAC_REFERENCE>, dim3(256), dim3(kThreadsSdf), lds, as_stream(stream),
+                           desc->lv, net, table, B_fourier, a, n_iters, (int64_t)2048, (int64_t)1024, scan_off, kSmall + 1,
+                           scan_hide);
+    else
+        hipLaunchKernelGGL(sdf_scan_secant_kernel<HM_FRAC_TRILINEAR>, dim3(256), dim3(kThreadsSdf), lds, as_stream(stream),
+                           desc->lv, net, table, B_fourier, a, n_iters, (int64_t)2048, (int64_t)1024, scan_off, kSmall + 1,
+                           scan_hide);
+    HM_CHECK_LAUNCH("hm_trace_scan_secant");
     return HM_OK;
 }
 

@@ -26,6 +26,12 @@ extern "C" int hm_trace_secant_persistent(const hm_grid_desc *desc, const hm_mlp
                                           const float *B_fourier, int frac_mode, int tile_points, const void *trace_args,
                                           int n_iters, void *stream);
 
+// hm_sdf.hip (not exported): the closest-approach scan and the secant refinement as ONE launch (workgroups without secant
+// rays start on the scan at once, 64-point tiles handed out by an atomic cursor)
+extern "C" int hm_trace_scan_secant(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *table,
+                                    const float *B_fourier, int frac_mode, const void *trace_args, int n_iters,
+                                    int64_t scan_off, int64_t scan_capacity, void *stream);
+
 namespace {
 
 constexpr int kTB = 256;
@@ -79,10 +85,10 @@ __global__ __launch_bounds__(kTB) void ray_samples_kernel(TraceArgs a, const int
     const int64_t gid = (int64_t)blockIdx.x * kTB + threadIdx.x;
     const TraceWs &w = a.w;
     const int32_t n_list = w.cnt[c_n];
-    const int64_t base = c_base >= 0 ? w.cnt[c_base] : 0;
+    const int64_t base = c_base == -2 ? a.sel_off : (c_base >= 0 ? w.cnt[c_base] : 0);   // (-2: the region of its own)
     if (gid == 0) {
         w.cnt[c_npts] = n_list * per_ray;
-        w.cnt[C_BIG_PTS] = (int32_t)base + n_list * per_ray;
+        if (c_base != -2) w.cnt[C_BIG_PTS] = (int32_t)base + n_list * per_ray;
     }
     const int64_t m = gid / per_ray;
     if (m >= n_list) return;
@@ -255,7 +261,8 @@ __global__ __launch_bounds__(kTB) void closest_reduce_kernel(TraceArgs a) {
     if (m >= w.cnt[C_NSEL]) return;
     const int64_t i = w.list_sel[m];
     const int n = a.n_steps;
-    const float *v = w.vals + (int64_t)w.cnt[a.head > 0 ? C_HEAD_PTS : C_NSAMP_PTS] + m * n;   // behind the sampler's first pass
+    const float *v = w.vals + (a.sel_off >= 0 ? a.sel_off : (int64_t)w.cnt[a.head > 0 ? C_HEAD_PTS : C_NSAMP_PTS]) +
+                     m * n;   // a region of their own, or behind the sampler's first pass
     int amin = 0, bad = !isfinite(v[0]);
     float best = v[0];
     if ((n & 3) == 0 && (reinterpret_cast<uintptr_t>(v) & 15u) == 0) {   // (16-byte loads: see sampler_reduce_kernel)
@@ -309,8 +316,8 @@ Layout make_layout(int64_t n, int n_steps, int emb_width = 0) {
     L.off_f = o; o = align_up(o + sizeof(float) * 13 * (size_t)n, 256);
     L.off_i = o; o = align_up(o + sizeof(int32_t) * 6 * (size_t)n, 256);
     L.off_b = o; o = align_up(o + 6 * (size_t)n, 256);
-    L.off_pts = o; o = align_up(o + sizeof(float) * 3 * 2 * (size_t)L.cap, 256);
-    L.off_vals = o; o = align_up(o + sizeof(float) * 2 * (size_t)L.cap, 256);
+    L.off_pts = o; o = align_up(o + sizeof(float) * 3 * 3 * (size_t)L.cap, 256);    // three regions of `cap` points
+    L.off_vals = o; o = align_up(o + sizeof(float) * 3 * (size_t)L.cap, 256);
     L.off_cnt = o; o = align_up(o + sizeof(int32_t) * C_COUNT, 256);
     L.off_emb = o; o = align_up(o + sizeof(float) * (size_t)emb_width * (size_t)L.cap, 256);   // (filter-bank embedders)
     L.total = o;
@@ -416,6 +423,15 @@ static int trace_forward_impl(const hm_grid_desc *desc, const hm_nffb_desc *nffb
     // lazy sampler: a first pass over samples 0..head-1 and n_steps-1 only pays when it leaves something out
     a.head = (cfg->sampler_head >= 1 && cfg->sampler_head + 1 < cfg->n_steps) ? cfg->sampler_head : 0;
     a.tail_off = L.cap;
+    // Closest-approach scan and secant refinement as one launch (hm_sdf.hip: sdf_scan_secant_kernel): training, hash-grid
+    // network, exact-fp32 coarse scans, tile size left to the library.  HM_TRACE_OVERLAP=0: the scan joins the sampler's
+    // launch and the secant runs behind it on a few dozen workgroups (A/B).
+    const char *e_ov = getenv("HM_TRACE_OVERLAP");      // (read per call: the tests compare both forms in one process)
+    const bool overlap_ok = !(e_ov && atoi(e_ov) == 0);
+    static const bool persistent_ok = [] { const char *e = getenv("HM_TRACE_PERSISTENT"); return !(e && atoi(e) == 0); }();
+    const bool overlap = overlap_ok && persistent_ok && cfg->training && !nffb && !cfg->coarse_bf16 && tile_points == 0 &&
+                         cfg->n_secant_steps > 0 && n_rays <= 8192;
+    a.sel_off = overlap ? 2 * L.cap : -1;
 
     hm_zero_u32_async(a.w.cnt, C_COUNT, st);
     const unsigned g_rays = (unsigned)((n_rays + kTB - 1) / kTB);
@@ -471,7 +487,6 @@ static int trace_forward_impl(const hm_grid_desc *desc, const hm_nffb_desc *nffb
     // it returns at once when no ray is left) instead of 30 (empty SDF launch, empty update launch) pairs.
     // HM_TRACE_PERSISTENT=0: every round a launch pair (A/B).
     const int rounds = 1 + cfg->sphere_tracing_iters * (1 + cfg->line_step_iters);
-    static const bool persistent_ok = [] { const char *e = getenv("HM_TRACE_PERSISTENT"); return !(e && atoi(e) == 0); }();
     const bool tail = persistent_ok && !nffb && (tile_points == 0 || tile_points == 16) &&
                       a.w.cap >= ((n_rays + 7) / 8) * 16 && cfg->line_step_iters > 0;
     int launched = tail ? 1 + cfg->sphere_tracing_iters : rounds;
@@ -506,12 +521,13 @@ static int trace_forward_impl(const hm_grid_desc *desc, const hm_nffb_desc *nffb
                        a.w.list_samp, (int)C_NSAMP, c_first, a.w.t_s, a.w.t_e, sampler_fracs, -1, per_ray);
     if (cfg->training)
         hipLaunchKernelGGL(ray_samples_kernel, dim3(g_samp), dim3(kTB), 0, st, a, a.w.list_sel, (int)C_NSEL,
-                           (int)C_NSEL_PTS, a.w.t_min, a.w.t_max, steps_u, c_first, cfg->n_steps);
+                           (int)C_NSEL_PTS, a.w.t_min, a.w.t_max, steps_u, overlap ? -2 : c_first, cfg->n_steps);
     {
-        int rc = coarse(0, n_rays * cfg->n_steps, a.w.cnt + C_BIG_PTS);
+        // (overlap: the sampler's points only - the closest-approach scan runs with the secant refinement below)
+        int rc = coarse(0, n_rays * cfg->n_steps, a.w.cnt + (overlap ? c_first : (int)C_BIG_PTS));
         if (rc != HM_OK) return rc;
     }
-    if (cfg->training) hipLaunchKernelGGL(closest_reduce_kernel, dim3(g_rays), dim3(kTB), 0, st, a);
+    if (cfg->training && !overlap) hipLaunchKernelGGL(closest_reduce_kernel, dim3(g_rays), dim3(kTB), 0, st, a);
     if (a.head > 0) {   // second pass: the remaining samples of the rays the head samples did not resolve
         hipLaunchKernelGGL(sampler_head_kernel, dim3(g_rays), dim3(kTB), 0, st, a);
         hipLaunchKernelGGL(sampler_tail_points_kernel, dim3(g_samp), dim3(kTB), 0, st, a);
@@ -523,8 +539,14 @@ static int trace_forward_impl(const hm_grid_desc *desc, const hm_nffb_desc *nffb
         hipLaunchKernelGGL(secant_points_kernel, dim3(g_rays), dim3(kTB), 0, st, a);
         // hash-grid networks with small-tile SDF launches (tile size left to the library, or 4 / 8 / 16) and a batch
         // small enough for them: all iterations as ONE launch in which a tile of secant rays stays with its workgroup
-        // (hm_sdf.hip: trace_secant_kernel); otherwise an (SDF launch, update launch) pair per iteration
-        if (persistent_ok && !nffb && (tile_points == 0 || tile_points == 4 || tile_points == 8 || tile_points == 16) &&
+        // (hm_sdf.hip: trace_secant_kernel; with the closest-approach scan in the same launch: sdf_scan_secant_kernel);
+        // otherwise an (SDF launch, update launch) pair per iteration
+        if (overlap) {
+            const int rc = hm_trace_scan_secant(desc, mlp, table, B_fourier, frac_mode, &a, cfg->n_secant_steps, a.sel_off,
+                                                n_rays * cfg->n_steps, stream);
+            if (rc != HM_OK) return rc;
+            hipLaunchKernelGGL(closest_reduce_kernel, dim3(g_rays), dim3(kTB), 0, st, a);
+        } else if (persistent_ok && !nffb && (tile_points == 0 || tile_points == 4 || tile_points == 8 || tile_points == 16) &&
             (tile_points != 0 || n_rays <= 8192)) {
             const int rc = hm_trace_secant_persistent(desc, mlp, table, B_fourier, frac_mode, tile_points, &a,
                                                       cfg->n_secant_steps, stream);

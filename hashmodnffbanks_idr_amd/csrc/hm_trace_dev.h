@@ -22,6 +22,7 @@ enum : int32_t {  // counters (device int32 array)
     C_NSAMP2 = 74,       // lazy sampler: rays whose first sign change is not among the head samples
     C_HEAD_PTS = 75,     // points of the sampler's first pass (= where the closest-approach values start)
     C_TAIL_PTS = 76,     // lazy sampler: points of the second pass
+    C_TILE_CURSOR = 77,  // sdf_scan_secant_kernel: next 64-point tile of the closest-approach scan (zero at launch)
     C_COUNT = 80
 };
 
@@ -57,7 +58,9 @@ struct TraceArgs {
     int32_t ls_iters, max_it, n_steps, n_secant, training;
     int32_t head;            // lazy sampler: samples 0..head-1 and n_steps-1 form the first pass (0 = all in one pass)
     int64_t tail_off;        // lazy sampler: where the second pass starts in pts / vals (host-known: the buffers are
-                             // sized for 2 * N * n_steps points)
+                             // sized for 3 * N * n_steps points)
+    int64_t sel_off;         // closest-approach points: their own (third) region of pts / vals when they are scanned by a
+                             // launch of their own (hm_trace_scan_secant); -1: behind the sampler's first pass
 };
 
 __device__ __forceinline__ void along(const TraceArgs &a, int64_t i, float t, float &px, float &py, float &pz) {

@@ -144,6 +144,52 @@ def test_device_tracer_equals_generic_tracer_C2(golden, mode, tile):
     assert st["sdf_evals"] > 2048 * 10 and st.get("nonfinite", 0) == 0
 
 
+@pytest.mark.parametrize("tag", ["bumpy", "C2"])
+@pytest.mark.parametrize("head", [0, 16])
+def test_scan_and_secant_in_one_launch(golden, tag, head, monkeypatch):
+    """Training searches with the tile size left to the library run the closest-approach scan and the secant refinement
+    as ONE launch (hm_sdf.hip: sdf_scan_secant_kernel - workgroups without secant rays start on the scan at once, its
+    64-point tiles are handed out by an atomic cursor); HM_TRACE_OVERLAP=0 is the form before it (the scan inside the
+    sampler's launch, the secant behind it).  The scan's values do not depend on who evaluates which tile: the
+    closest-approach results must be bit-identical.  The secant runs on 16-point tiles under a long scan and on 4 / 8-point
+    ones alone (different MFMA shapes, ~1e-7 apart; the secant steps amplify that on a bumpy surface: 2e-5 seen): its
+    rays agree to 1e-4 relative, the network mask may flip for a ray at the threshold.  Both sampler forms (head = 0: single pass, 16: lazy)."""
+    from hashmodnffbanks_idr_amd.model.ray_tracing import RayTracing
+    import params as P
+    g = golden(f"raytrace_{tag}")
+    net = _net(g, tag)
+    net.eval()
+    net.sdf_tile_points = 0
+    n_rays = 2048
+    cam, dirs = P.make_rays(21, n_rays)
+    om = np.random.RandomState(21).uniform(0, 1, n_rays) < 0.6
+    outs, stats = [], []
+    for ov in ("1", "0"):
+        monkeypatch.setenv("HM_TRACE_OVERLAP", ov)
+        rt = RayTracing(1.0, 5.0e-5, 0.5, 3, 10, 100, 8).cuda()
+        rt.train(True)
+        rt.sampler_head = head
+        rt.steps_override = torch.from_numpy(g["steps"])
+        with torch.no_grad():
+            outs.append(rt(sdf=net.sdf, cam_loc=torch.from_numpy(cam).cuda(), object_mask=torch.from_numpy(om).cuda(),
+                           ray_directions=torch.from_numpy(dirs).cuda()))
+        stats.append(dict(rt.last_stats))
+    (p1, m1, d1), (p2, m2, d2) = outs
+    s1, s2 = stats
+    print(f"{tag} head {head}: stats {s1}")
+    assert s1["unfinished"] == 0 and s1.get("nonfinite", 0) == 0
+    assert s1["sdf_evals"] == s2["sdf_evals"] and s1["mask_loss_rays"] == s2["mask_loss_rays"] > 80   # (> 8192 scan points)
+    flips = int((m1 != m2).sum())
+    assert flips <= 2
+    miss = ~m1 & ~m2
+    assert torch.equal(d1[miss], d2[miss]) and torch.equal(p1[miss], p2[miss])      # closest approach / sphere misses
+    hit = m1 & m2
+    dd = (d1 - d2)[hit].abs()
+    print(f"  {int(hit.sum())} common hits, max |d dist| {float(dd.max()):.3e}, bit-equal {float((dd == 0).float().mean()):.3f}, "
+          f"{flips} mask flips")
+    assert float((dd / (1.0 + d2[hit].abs())).max()) <= 1e-4      # (the tile-0 criterion of _device_vs_host)
+
+
 @pytest.mark.parametrize("tag,n_rays", [("bumpy", None), ("bumpy", 2048), ("C2", None)])
 def test_persistent_march_tail_carries_whole_marches(golden, tag, n_rays, monkeypatch):
     """hm_sdf.hip: trace_march_tail_kernel normally takes over after the 1 + sphere_tracing_iters guaranteed rounds and
