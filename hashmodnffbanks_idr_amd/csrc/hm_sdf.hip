@@ -65,6 +65,34 @@ constexpr int kThreadsSdf = 512;
 constexpr int kWaves = 8;
 constexpr int kGroupFloats = kPts * 4;  // floats per k-group row of X: [point][4]
 
+// Filler tiles.  A launch whose own points end in a partly filled last round can take the 64-point tiles that complete
+// the round from a SECOND point set that has to be evaluated anyway (the ray search: the closest-approach scan, whose
+// values nothing in the sampler's launches waits for).  Which of that set's tiles a launch takes follows from the
+// device-side counts alone, the same way in every launch of the chain: a launch with TA own tiles on G workgroups takes
+// pad = (G - TA mod G) mod G filler tiles if that many are still available and it runs on the 64-point kernel at all,
+// none otherwise (its remainder then follows the half-tile rule).
+struct SdfFill {               // resolved, per launch
+    const float *x;
+    float *out;
+    int64_t n;                 // points of the filler set
+    int64_t tile0;             // its first tile that is still free
+};
+struct SdfFillArgs {           // kernel argument (all zero: no filler)
+    const float *x;
+    float *out;
+    const int32_t *n_dev;      // device-side point count of the filler set
+    const int32_t *prev_dev;   // own-point count of the launch that took filler tiles before this one (or NULL)
+    int32_t prev_grid;
+    int32_t pad_;
+};
+
+__device__ __forceinline__ int64_t fill_quota(int64_t n_own, int64_t grid, int64_t avail, int64_t run_min) {
+    if (n_own < run_min || grid <= 0) return 0;
+    const int64_t ta = (n_own + 63) / 64;
+    const int64_t pad = (grid - ta % grid) % grid;
+    return (pad > 0 && avail >= pad) ? pad : 0;
+}
+
 // The 64-point tile loop of sdf_fwd_kernel / sdf_scan_secant_kernel.  DYN = false: the static schedule below
 // (tile = round * grid + workgroup); DYN = true: the SAME tiles in the same enumeration, handed out by an atomic cursor
 // (zero at launch) - workgroups that start late (they carried secant rays first) simply take fewer of them.
@@ -72,7 +100,7 @@ template <int FRAC, bool DYN>
 __device__ __forceinline__ void sdf64_run(const HmLevels &lv, const SdfNet &net, const float *__restrict__ x, int64_t n,
                                           const float *__restrict__ table, const float *__restrict__ Bf,
                                           float *__restrict__ out, int64_t out_stride, int out_cols, float *lds,
-                                          unsigned *cursor) {
+                                          unsigned *cursor, const SdfFill &fb) {
     __shared__ unsigned s_next_tile;
     float *X = lds;
     float *EMB = lds + (size_t)net.x_groups * kGroupFloats;
@@ -92,7 +120,10 @@ __device__ __forceinline__ void sdf64_run(const HmLevels &lv, const SdfNet &net,
     // the chip: 204 800 points on 256 CUs are 12 rounds + 256 half tiles instead of 13 rounds on 128 CUs.  A point's
     // value does not depend on the tile it sits in (tests: permutation equivariance bit for bit).
     const int64_t G = gridDim.x;
-    const int64_t rounds = (n / kPts) / G;
+    // filler tiles (static schedule only): TA own tiles, then tiles fb.tile0 .. of the second set up to the end of the round
+    const int64_t TA = (n + kPts - 1) / kPts;
+    const int64_t n_fill = DYN ? 0 : fill_quota(n, G, max((fb.n + kPts - 1) / kPts - fb.tile0, (int64_t)0), 0);
+    const int64_t rounds = n_fill > 0 ? (TA + n_fill) / G : (n / kPts) / G;
     const int64_t rem_base = rounds * G * kPts;
     const int64_t rem_step = (n - rem_base <= G * 32) ? 32 : kPts;
 
@@ -109,7 +140,21 @@ __device__ __forceinline__ void sdf64_run(const HmLevels &lv, const SdfNet &net,
         if (itr > rounds) break;
         int64_t base;
         int cnt;
-        if (itr < rounds) {
+        const float *__restrict__ xs = x;       // this tile's point set
+        float *__restrict__ os = out;
+        if (n_fill > 0) {                        // whole rounds: own tiles (the last one may be ragged), then filler tiles
+            if (itr == rounds) break;
+            const int64_t v = itr * G + wg;
+            if (v < TA) {
+                base = v * kPts;
+                cnt = (int)min((int64_t)kPts, n - base);
+            } else {
+                base = (fb.tile0 + (v - TA)) * kPts;
+                cnt = (int)min((int64_t)kPts, fb.n - base);
+                xs = fb.x;
+                os = fb.out;
+            }
+        } else if (itr < rounds) {
             base = (itr * G + wg) * kPts;
             cnt = kPts;
         } else {
@@ -120,12 +165,12 @@ __device__ __forceinline__ void sdf64_run(const HmLevels &lv, const SdfNet &net,
         const bool half = cnt <= 32;   // (also a ragged last tile of <= 32 points)
         HM_PROBE(0);
         __syncthreads();  // previous tile's output stage is done with X
-        if (FRAC != kFracEmb && tid < kPts * 3) SX[tid] = (tid < cnt * 3) ? x[base * 3 + tid] : 0.0f;
+        if (FRAC != kFracEmb && tid < kPts * 3) SX[tid] = (tid < cnt * 3) ? xs[base * 3 + tid] : 0.0f;
         __syncthreads();
 
         // ---------------- encode -> EMB[(e/4)][p][e%4] ------------------------------------
         if constexpr (FRAC == kFracEmb) {
-            load_emb_tile(EMB, x, net.emb_stride, base, cnt, E, net.emb_groups, kPts, kGroupFloats, tid, kThreadsSdf);
+            load_emb_tile(EMB, xs, net.emb_stride, base, cnt, E, net.emb_groups, kPts, kGroupFloats, tid, kThreadsSdf);
         } else {
             const int p = tid & (kPts - 1);
             const int grp = tid >> 6;  // 0..7
@@ -223,7 +268,7 @@ __device__ __forceinline__ void sdf64_run(const HmLevels &lv, const SdfNet &net,
                 if (tid < cnt) {
                     float sacc = Ly.bias[0];
                     for (int w8 = 0; w8 < kWaves; ++w8) sacc += RED[w8 * kPts + tid];
-                    out[(base + tid) * out_stride] = sdf_clamp(sacc, net.beta);
+                    os[(base + tid) * out_stride] = sdf_clamp(sacc, net.beta);
                 }
                 break;
             }
@@ -390,7 +435,7 @@ __device__ __forceinline__ void sdf64_run(const HmLevels &lv, const SdfNet &net,
                 const int p = i / od, f = i - p * od;
                 float v = X[(f >> 2) * kGroupFloats + p * 4 + (f & 3)];
                 if (f == 0) v = sdf_clamp(v, net.beta);
-                out[(base + p) * out_stride + f] = v;
+                os[(base + p) * out_stride + f] = v;
             }
         }
     }
@@ -403,11 +448,19 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void sdf_fwd_kernel(HmLevels lv, Sd
                                                                   const float *__restrict__ Bf,
                                                                   float *__restrict__ out, int64_t out_stride,
                                                                   int out_cols, const int32_t *__restrict__ n_dev, int64_t run_min,
-                                                                  int64_t run_max) {
+                                                                  int64_t run_max, SdfFillArgs fa) {
     extern __shared__ __align__(16) float lds[];
     if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));  // device-side point count (sync-free callers)
     if (n < run_min || n > run_max) return;          // the other tile-size kernel owns this batch size
-    sdf64_run<FRAC, false>(lv, net, x, n, table, Bf, out, out_stride, out_cols, lds, nullptr);
+    SdfFill fb = {nullptr, nullptr, 0, 0};
+    if (fa.n_dev) {
+        fb.x = fa.x;
+        fb.out = fa.out;
+        fb.n = max(*fa.n_dev, 0);
+        if (fa.prev_dev)
+            fb.tile0 = fill_quota(max(*fa.prev_dev, 0), fa.prev_grid, (fb.n + kPts - 1) / kPts, run_min);
+    }
+    sdf64_run<FRAC, false>(lv, net, x, n, table, Bf, out, out_stride, out_cols, lds, nullptr, fb);
 }
 
 
@@ -1341,7 +1394,8 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void sdf_scan_secant_kernel(HmLevel
                                                                           const float *__restrict__ Bf, TraceArgs a,
                                                                           int n_iters, int64_t m8_max, int64_t m4_max,
                                                                           int64_t scan_off, int64_t scan_min,
-                                                                          int64_t scan_hide) {
+                                                                          int64_t scan_hide, int c_prev1, int grid1,
+                                                                          int c_prev2, int grid2) {
     extern __shared__ __align__(16) float lds[];
     const int64_t n_scan = max(a.w.cnt[C_NSEL_PTS], 0);
     const int64_t n_sec = a.w.cnt[C_NSEC];
@@ -1350,8 +1404,15 @@ __global__ __launch_bounds__(kThreadsSdf, 2) void sdf_scan_secant_kernel(HmLevel
         secant_role<FRAC>(lv, net, table, Bf, a, n_iters, n_sec, pts, lds);
     }
     if (n_scan < scan_min) return;        // (a short scan is the small-tile launch's job)
-    sdf64_run<FRAC, true>(lv, net, a.w.pts + scan_off * 3, n_scan, table, Bf, a.w.vals + scan_off, 1, 1, lds,
-                          reinterpret_cast<unsigned *>(a.w.cnt + C_TILE_CURSOR));
+    // the scan's first tiles completed the last rounds of the sampler's launches (filler tiles, see fill_quota)
+    const int64_t tb = (n_scan + kPts - 1) / kPts;
+    int64_t done = c_prev1 >= 0 ? fill_quota(max(a.w.cnt[c_prev1], 0), grid1, tb, scan_min) : 0;
+    if (c_prev2 >= 0) done += fill_quota(max(a.w.cnt[c_prev2], 0), grid2, tb - done, scan_min);
+    const int64_t skip = done * kPts;
+    if (skip >= n_scan) return;
+    const SdfFill none = {nullptr, nullptr, 0, 0};
+    sdf64_run<FRAC, true>(lv, net, a.w.pts + (scan_off + skip) * 3, n_scan - skip, table, Bf, a.w.vals + scan_off + skip, 1, 1,
+                          lds, reinterpret_cast<unsigned *>(a.w.cnt + C_TILE_CURSOR), none);
 }
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
@@ -1375,7 +1436,23 @@ HM_API int hm_probe_read(unsigned long long *out, int n) {
 
 static int sdf_fwd_impl(const HmLevels &lv, const hm_mlp_desc *mlp, const float *x, int64_t emb_stride, int64_t n,
                         const float *table, const float *B_fourier, float *out, int64_t out_stride, int out_cols,
-                        int frac_mode, int tile_points, const int32_t *n_dev, int max_workgroups, void *stream);
+                        int frac_mode, int tile_points, const int32_t *n_dev, int max_workgroups, void *stream,
+                        const SdfFillArgs *fill = nullptr, int *grid64_out = nullptr);
+
+// hm_sdf_fwd for the ray search's sampler launches (not exported): the 64-point launch completes its last round with
+// tiles of a second point set (fill_quota; x_fill / out_fill / n_fill_dev: the closest-approach scan's points, values and
+// device-side count; prev_dev / prev_grid: own-point count and grid of the launch that took filler tiles before this one).
+// *grid64_out = the 64-point launch's grid (0: there was none), for the next launch of the chain.
+int hm_sdf_fwd_fill(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *x, int64_t n, const float *table,
+                    const float *B_fourier, float *out, int frac_mode, const int32_t *n_dev, const float *x_fill,
+                    float *out_fill, const int32_t *n_fill_dev, const int32_t *prev_dev, int prev_grid, int *grid64_out,
+                    void *stream) {
+    HM_CHECK_ARG(desc && mlp, "hm_sdf_fwd_fill: NULL descriptor");
+    HM_CHECK_ARG(n == 0 || (table && B_fourier && n_dev && x_fill && out_fill && n_fill_dev), "hm_sdf_fwd_fill: NULL pointer");
+    SdfFillArgs fa = {x_fill, out_fill, n_fill_dev, prev_grid > 0 ? prev_dev : nullptr, prev_grid, 0};
+    if (grid64_out) *grid64_out = 0;
+    return sdf_fwd_impl(desc->lv, mlp, x, 0, n, table, B_fourier, out, 1, 1, frac_mode, 0, n_dev, 0, stream, &fa, grid64_out);
+}
 
 int hm_sdf_fwd(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *x, int64_t n, const float *table,
                const float *B_fourier, float *out, int64_t out_stride, int out_cols, int frac_mode, int tile_points,
@@ -1533,7 +1610,7 @@ int hm_trace_secant_persistent(const hm_grid_desc *desc, const hm_mlp_desc *mlp,
 // (sdf_scan_secant_kernel); scans of <= 8192 points run on the small-tile launch in front of it.  tile_points = 0 only.
 int hm_trace_scan_secant(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *table, const float *B_fourier,
                          int frac_mode, const void *trace_args, int n_iters, int64_t scan_off, int64_t scan_capacity,
-                         void *stream) {
+                         int c_prev1, int grid1, int c_prev2, int grid2, void *stream) {
     HM_CHECK_ARG(desc && mlp && table && B_fourier && trace_args, "hm_trace_scan_secant: NULL argument");
     HM_CHECK_ARG(frac_mode == HM_FRAC_REFERENCE || frac_mode == HM_FRAC_TRILINEAR, "hm_trace_scan_secant: bad frac_mode");
     const TraceArgs &a = *static_cast<const TraceArgs *>(trace_args);
@@ -1567,21 +1644,24 @@ int hm_trace_scan_secant(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const
     // 16-point secant tiles once the scan keeps the chip busy for longer than their chain takes (8 x 131 us ~ 2.3 rounds
     // of 64-point tiles: 3 rounds = 49 152 points)
     const int64_t scan_hide = 3 * 256 * kPts;
+    // c_prev*: counters holding the own-point counts of the sampler launches that took filler tiles of this scan (-1: none)
+    const int p1 = grid1 > 0 ? c_prev1 : -1, p2 = grid2 > 0 ? c_prev2 : -1;
     if (frac_mode == HM_FRAC_REFERENCE)
         hipLaunchKernelGGL(sdf_scan_secant_kernel<HM_FRAC_REFERENCE>, dim3(256), dim3(kThreadsSdf), lds, as_stream(stream),
                            desc->lv, net, table, B_fourier, a, n_iters, (int64_t)2048, (int64_t)1024, scan_off, kSmall + 1,
-                           scan_hide);
+                           scan_hide, p1, grid1, p2, grid2);
     else
         hipLaunchKernelGGL(sdf_scan_secant_kernel<HM_FRAC_TRILINEAR>, dim3(256), dim3(kThreadsSdf), lds, as_stream(stream),
                            desc->lv, net, table, B_fourier, a, n_iters, (int64_t)2048, (int64_t)1024, scan_off, kSmall + 1,
-                           scan_hide);
+                           scan_hide, p1, grid1, p2, grid2);
     HM_CHECK_LAUNCH("hm_trace_scan_secant");
     return HM_OK;
 }
 
 static int sdf_fwd_impl(const HmLevels &lv, const hm_mlp_desc *mlp, const float *x, int64_t emb_stride, int64_t n,
                         const float *table, const float *B_fourier, float *out, int64_t out_stride, int out_cols,
-                        int frac_mode, int tile_points, const int32_t *n_dev, int max_workgroups, void *stream) {
+                        int frac_mode, int tile_points, const int32_t *n_dev, int max_workgroups, void *stream,
+                        const SdfFillArgs *fill, int *grid64_out) {
     HM_CHECK_ARG(mlp, "hm_sdf_fwd: NULL descriptor");
     HM_CHECK_ARG(n >= 0, "hm_sdf_fwd: n < 0");
     HM_CHECK_ARG(frac_mode == HM_FRAC_REFERENCE || frac_mode == HM_FRAC_TRILINEAR, "hm_sdf_fwd: bad frac_mode");
@@ -1721,18 +1801,22 @@ static int sdf_fwd_impl(const HmLevels &lv, const hm_mlp_desc *mlp, const float 
         const int64_t tiles = (n + 31) / 32;      // (up to cap * 32 points: one 32-point half tile per workgroup)
         const int64_t cap = max_workgroups > 0 ? max_workgroups : 256;
         const int64_t grid = tiles < cap ? tiles : cap;
+        // filler tiles only where every launch of the chain applies the same lower bound (fill_quota's run_min)
+        const SdfFillArgs none = {nullptr, nullptr, nullptr, nullptr, 0, 0};
+        const SdfFillArgs fa = (fill && lo64 == kSmall + 1 && out_cols == 1 && out_stride == 1) ? *fill : none;
+        if (grid64_out && fa.n_dev) *grid64_out = (int)grid;
         if (mode == kFracEmb)
             hipLaunchKernelGGL(sdf_fwd_kernel<kFracEmb>, dim3((unsigned)grid), dim3(kThreadsSdf), lds,
                                as_stream(stream), lv, net, x, n, table, B_fourier, out, out_stride, out_cols, n_dev,
-                               lo64, hi64);
+                               lo64, hi64, none);
         else if (mode == HM_FRAC_REFERENCE)
             hipLaunchKernelGGL(sdf_fwd_kernel<HM_FRAC_REFERENCE>, dim3((unsigned)grid), dim3(kThreadsSdf), lds,
                                as_stream(stream), lv, net, x, n, table, B_fourier, out, out_stride, out_cols, n_dev,
-                               lo64, hi64);
+                               lo64, hi64, fa);
         else
             hipLaunchKernelGGL(sdf_fwd_kernel<HM_FRAC_TRILINEAR>, dim3((unsigned)grid), dim3(kThreadsSdf), lds,
                                as_stream(stream), lv, net, x, n, table, B_fourier, out, out_stride, out_cols, n_dev,
-                               lo64, hi64);
+                               lo64, hi64, fa);
     }
     HM_CHECK_LAUNCH("hm_sdf_fwd");
     return HM_OK;

@@ -30,7 +30,14 @@ extern "C" int hm_trace_secant_persistent(const hm_grid_desc *desc, const hm_mlp
 // rays start on the scan at once, 64-point tiles handed out by an atomic cursor)
 extern "C" int hm_trace_scan_secant(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *table,
                                     const float *B_fourier, int frac_mode, const void *trace_args, int n_iters,
-                                    int64_t scan_off, int64_t scan_capacity, void *stream);
+                                    int64_t scan_off, int64_t scan_capacity, int c_prev1, int grid1, int c_prev2,
+                                    int grid2, void *stream);
+
+// hm_sdf.hip (not exported): hm_sdf_fwd whose 64-point launch completes its last round with tiles of a second point set
+extern "C" int hm_sdf_fwd_fill(const hm_grid_desc *desc, const hm_mlp_desc *mlp, const float *x, int64_t n,
+                               const float *table, const float *B_fourier, float *out, int frac_mode, const int32_t *n_dev,
+                               const float *x_fill, float *out_fill, const int32_t *n_fill_dev, const int32_t *prev_dev,
+                               int prev_grid, int *grid64_out, void *stream);
 
 namespace {
 
@@ -522,16 +529,27 @@ static int trace_forward_impl(const hm_grid_desc *desc, const hm_nffb_desc *nffb
     if (cfg->training)
         hipLaunchKernelGGL(ray_samples_kernel, dim3(g_samp), dim3(kTB), 0, st, a, a.w.list_sel, (int)C_NSEL,
                            (int)C_NSEL_PTS, a.w.t_min, a.w.t_max, steps_u, overlap ? -2 : c_first, cfg->n_steps);
-    {
-        // (overlap: the sampler's points only - the closest-approach scan runs with the secant refinement below)
-        int rc = coarse(0, n_rays * cfg->n_steps, a.w.cnt + (overlap ? c_first : (int)C_BIG_PTS));
+    int grid_p1 = 0, grid_p2 = 0;      // overlap: grids of the sampler launches that took filler tiles of the scan
+    if (overlap) {
+        // the sampler's points only - the closest-approach scan runs with the secant refinement below, except for the
+        // tiles that complete the last round of this launch (hm_sdf.hip: fill_quota)
+        int rc = hm_sdf_fwd_fill(desc, mlp, a.w.pts, n_rays * cfg->n_steps, table, B_fourier, a.w.vals, frac_mode,
+                                 a.w.cnt + c_first, a.w.pts + a.sel_off * 3, a.w.vals + a.sel_off, a.w.cnt + C_NSEL_PTS,
+                                 nullptr, 0, &grid_p1, stream);
+        if (rc != HM_OK) return rc;
+    } else {
+        int rc = coarse(0, n_rays * cfg->n_steps, a.w.cnt + C_BIG_PTS);
         if (rc != HM_OK) return rc;
     }
     if (cfg->training && !overlap) hipLaunchKernelGGL(closest_reduce_kernel, dim3(g_rays), dim3(kTB), 0, st, a);
     if (a.head > 0) {   // second pass: the remaining samples of the rays the head samples did not resolve
         hipLaunchKernelGGL(sampler_head_kernel, dim3(g_rays), dim3(kTB), 0, st, a);
         hipLaunchKernelGGL(sampler_tail_points_kernel, dim3(g_samp), dim3(kTB), 0, st, a);
-        int rc = coarse(a.tail_off, n_rays * (cfg->n_steps - a.head - 1), a.w.cnt + C_TAIL_PTS);
+        int rc = overlap ? hm_sdf_fwd_fill(desc, mlp, a.w.pts + a.tail_off * 3, n_rays * (cfg->n_steps - a.head - 1), table,
+                                           B_fourier, a.w.vals + a.tail_off, frac_mode, a.w.cnt + C_TAIL_PTS,
+                                           a.w.pts + a.sel_off * 3, a.w.vals + a.sel_off, a.w.cnt + C_NSEL_PTS,
+                                           a.w.cnt + c_first, grid_p1, &grid_p2, stream)
+                         : coarse(a.tail_off, n_rays * (cfg->n_steps - a.head - 1), a.w.cnt + C_TAIL_PTS);
         if (rc != HM_OK) return rc;
     }
     hipLaunchKernelGGL(sampler_reduce_kernel, dim3(g_rays), dim3(kTB), 0, st, a);
@@ -543,7 +561,7 @@ static int trace_forward_impl(const hm_grid_desc *desc, const hm_nffb_desc *nffb
         // otherwise an (SDF launch, update launch) pair per iteration
         if (overlap) {
             const int rc = hm_trace_scan_secant(desc, mlp, table, B_fourier, frac_mode, &a, cfg->n_secant_steps, a.sel_off,
-                                                n_rays * cfg->n_steps, stream);
+                                                n_rays * cfg->n_steps, c_first, grid_p1, (int)C_TAIL_PTS, grid_p2, stream);
             if (rc != HM_OK) return rc;
             hipLaunchKernelGGL(closest_reduce_kernel, dim3(g_rays), dim3(kTB), 0, st, a);
         } else if (persistent_ok && !nffb && (tile_points == 0 || tile_points == 4 || tile_points == 8 || tile_points == 16) &&
