@@ -190,6 +190,51 @@ def test_scan_and_secant_in_one_launch(golden, tag, head, monkeypatch):
     assert float((dd / (1.0 + d2[hit].abs())).max()) <= 1e-4      # (the tile-0 criterion of _device_vs_host)
 
 
+@pytest.mark.parametrize("n_rays", [77, 300, 2048])
+@pytest.mark.parametrize("case", ["plain", "all_miss_sphere", "mask_all_false", "mask_all_true"])
+def test_scan_and_secant_in_one_launch_edge_cases(golden, case, n_rays, monkeypatch):
+    """The one-launch form (see test_scan_and_secant_in_one_launch) where one of its parts is empty or small: no secant
+    ray at all (every ray misses the sphere), every ray a mask-loss ray (the scan is the whole coarse work, the sampler's
+    launch has no point of its own and takes no filler tile), no mask-loss ray (empty scan), 77 rays (all launches on the
+    small-tile kernels) and 300 (scan above, sampler possibly below the 64-point kernel's range)."""
+    from hashmodnffbanks_idr_amd.model.ray_tracing import RayTracing
+    import params as P
+    g = golden("raytrace_bumpy")
+    net = _net(g, "bumpy")
+    net.eval()
+    net.sdf_tile_points = 0
+    cam, dirs = P.make_rays(31, n_rays)
+    om = np.random.RandomState(31).uniform(0, 1, n_rays) < 0.6
+    if case == "all_miss_sphere":
+        dirs = -dirs
+    if case == "mask_all_false":
+        om[:] = False
+    if case == "mask_all_true":
+        om[:] = True
+    outs, stats = [], []
+    for ov in ("1", "0"):
+        monkeypatch.setenv("HM_TRACE_OVERLAP", ov)
+        rt = RayTracing(1.0, 5.0e-5, 0.5, 3, 10, 100, 8).cuda()
+        rt.train(True)
+        rt.steps_override = torch.from_numpy(g["steps"])
+        with torch.no_grad():
+            outs.append(rt(sdf=net.sdf, cam_loc=torch.from_numpy(cam).cuda(), object_mask=torch.from_numpy(om).cuda(),
+                           ray_directions=torch.from_numpy(np.ascontiguousarray(dirs)).cuda()))
+        stats.append(dict(rt.last_stats))
+    (p1, m1, d1), (p2, m2, d2) = outs
+    s1, s2 = stats
+    assert s1["unfinished"] == 0 and s1.get("nonfinite", 0) == 0 and s1["sdf_evals"] == s2["sdf_evals"]
+    assert int((m1 != m2).sum()) <= 1
+    both = (m1 == m2)
+    rel = ((d1 - d2).abs() / (1.0 + d2.abs()))[both]
+    assert rel.numel() == 0 or float(rel.max()) <= 1e-4
+    if s1["mask_loss_rays"] * 100 > 8192 and (s1["sampler_points"] + s1["mask_loss_rays"] * 100) > 8192:
+        miss = ~m1 & ~m2          # both forms scan on the 64-point kernel: bit-identical closest-approach results
+        assert torch.equal(d1[miss], d2[miss]) and torch.equal(p1[miss], p2[miss])
+    if case == "all_miss_sphere":
+        assert not bool(m1.any()) and s1["secant_rays"] == 0
+
+
 @pytest.mark.parametrize("tag,n_rays", [("bumpy", None), ("bumpy", 2048), ("C2", None)])
 def test_persistent_march_tail_carries_whole_marches(golden, tag, n_rays, monkeypatch):
     """hm_sdf.hip: trace_march_tail_kernel normally takes over after the 1 + sphere_tracing_iters guaranteed rounds and
