@@ -14,15 +14,24 @@ loss_fn = IDRLoss(eikonal_weight=0.1, mask_weight=100.0, alpha=50.0)
 opt = torch.optim.Adam(model.parameters(), lr=1.0e-4)
 inp, gt = bench.synthetic_batch(1234, 2048, dev)
 torch.manual_seed(100)
+
+
+def counters(ws, n, n_steps=100):
+    """the int32 counter block of the tracer workspace (csrc/hm_trace.hip: make_layout)"""
+    al = lambda o: (o + 255) // 256 * 256  # noqa: E731
+    cap = n * n_steps
+    o = al(4 * 13 * n)
+    o = al(o + 4 * 6 * n)
+    o = al(o + 6 * n)
+    o = al(o + 4 * 3 * 3 * cap)
+    o = al(o + 4 * 3 * cap)
+    return ws.view(torch.uint8)[o:o + 4 * 80].view(torch.int32).cpu()
+
+
 for step in range(int(sys.argv[1]) if len(sys.argv) > 1 else 1):
     parallel.train_step(model, loss_fn, opt, inp, gt, None)
-    if step in (0, 20, 100, 299):
+    if step in (0, 20, 100, 200, 299):
         torch.cuda.synchronize()
         st = model.ray_tracer.last_stats
-        v = model.ray_tracer._ws.view(torch.int32).cpu()
-        ns = st["sampler_rays"]
-        hit = ((v[:-2] == ns) & (v[1:-1] == ns * 100) & (v[2:] == st["secant_rays"])).nonzero().flatten()
-        for h in hit.tolist():
-            if h >= 64 and int(v[h - 64]) == 4096:
-                print("step", step, st, "rounds:", [int(c) for c in v[h - 64:h - 64 + 42]], flush=True)
-                break
+        c = counters(model.ray_tracer._ws, 2048)
+        print("step", step, st, "rounds:", [int(v) for v in c[:42]], flush=True)
