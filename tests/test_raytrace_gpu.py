@@ -144,6 +144,41 @@ def test_device_tracer_equals_generic_tracer_C2(golden, mode, tile):
     assert st["sdf_evals"] > 2048 * 10 and st.get("nonfinite", 0) == 0
 
 
+@pytest.mark.parametrize("tile", [0, 16, 64])
+def test_device_tracer_equals_generic_tracer_trilinear(golden, tile):
+    """frac_mode = 'trilinear' (the opt-in interpolating encoder): the device tracer - its TRILINEAR kernel instantiations,
+    with tile 0 the one-launch scan + secant form and the filler tiles - against the generic tracer on the same ops,
+    training mode, 2048 rays: bit for bit at fixed tile sizes, the tile-0 criterion of _device_vs_host otherwise."""
+    from hashmodnffbanks_idr_amd.model.ray_tracing import RayTracing
+    import params as P
+    g = golden("raytrace_bumpy")
+    net = _net(g, "bumpy")
+    net.embed_model.embedder_obj.frac_mode = "trilinear"
+    net.eval()
+    net.sdf_tile_points = tile
+    cam, dirs = P.make_rays(17, 2048)
+    om = np.random.RandomState(17).uniform(0, 1, 2048) < 0.7
+    outs = []
+    for dev_tracer in (True, False):
+        rt = RayTracing(1.0, 5.0e-5, 0.5, 3, 10, 100, 8).cuda()
+        rt.train(True)
+        rt.use_device_tracer = dev_tracer
+        rt.steps_override = torch.from_numpy(g["steps"])
+        with torch.no_grad():
+            outs.append(rt(sdf=net.sdf, cam_loc=torch.from_numpy(cam).cuda(), object_mask=torch.from_numpy(om).cuda(),
+                           ray_directions=torch.from_numpy(dirs).cuda()))
+        if dev_tracer:
+            assert rt.last_stats["unfinished"] == 0 and rt.last_stats.get("nonfinite", 0) == 0
+            assert rt.last_stats["mask_loss_rays"] * 100 > 8192
+    (p1, m1, d1), (p2, m2, d2) = outs
+    if tile == 0:
+        assert int((m1 != m2).sum()) <= 10
+        rel = ((d1 - d2).abs() / (1.0 + d2.abs()))
+        assert float((rel > 1e-4).float().mean()) <= 0.01
+    else:
+        assert torch.equal(m1, m2) and torch.equal(d1, d2) and torch.equal(p1, p2)
+
+
 @pytest.mark.parametrize("tag", ["bumpy", "C2"])
 @pytest.mark.parametrize("head", [0, 16])
 def test_scan_and_secant_in_one_launch(golden, tag, head, monkeypatch):
