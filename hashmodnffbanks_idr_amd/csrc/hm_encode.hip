@@ -25,17 +25,25 @@ namespace {
 constexpr int kTile = 64;  // points per workgroup
 constexpr int kThreads = 256;
 
-__device__ __forceinline__ float dpp_add_xor1(float v) {
-    int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
-    return v + __int_as_float(t);
-}
-__device__ __forceinline__ float dpp_add_xor2(float v) {
-    int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
-    return v + __int_as_float(t);
-}
-__device__ __forceinline__ float dpp_add_half_mirror(float v) {
-    int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false);  // row_half_mirror
-    return v + __int_as_float(t);
+// v + (v of the partner lane) as ONE VALU instruction per step (v_add_f32 with a DPP-permuted operand).  The builtin form
+// (__builtin_amdgcn_update_dpp + an add) compiled to v_mov_b32 + v_mov_b32_dpp + a packed add per step - with the wait states
+// 18 issue slots of the ~40 of a (level, point group) pass in the gather kernels, which are VALU-bound (r3bj).  The
+// s_nop covers the two wait states a DPP read needs behind the VALU write of its source (the assembler does not insert
+// them for inline code); the sum is the same IEEE addition, bit for bit.
+__device__ __forceinline__ void dpp_sum8_pair(float &a0, float &a1) {
+    // sums over the 8 corner lanes of a point (lanes 8p .. 8p+7 of a row of 16): partner lane ^1, ^2, then the other quad of
+    // the half row - the order of the additions the builtin form had.  Two independent chains: one filler instruction and
+    // one s_nop give the second wait state between a value's steps.
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf"
+        : "+v"(a0), "+v"(a1));
 }
 
 // Output-tile store with a cache policy (flags bits 0-1): 0 plain, 1 write-through `sc1` (the line is DROPPED from the
@@ -146,9 +154,7 @@ __global__ __launch_bounds__(kThreads) void encode_fwd_f2_kernel(HmLevels lv, co
             for (int j = 0; j < 8; ++j) {
                 float a0 = __fmul_rn(v[j].x, w[j]);
                 float a1 = __fmul_rn(v[j].y, w[j]);
-                a0 = dpp_add_xor1(a0); a1 = dpp_add_xor1(a1);
-                a0 = dpp_add_xor2(a0); a1 = dpp_add_xor2(a1);
-                a0 = dpp_add_half_mirror(a0); a1 = dpp_add_half_mirror(a1);
+                dpp_sum8_pair(a0, a1);
                 if (corner == 0) {
                     const int p = j * 8 + sub;
                     float *o = s_out + p * E + hoff + 2 * l;
@@ -272,9 +278,7 @@ __global__ __launch_bounds__(kThreadsS) void encode_fwd_f2_sweep_kernel(HmLevels
                 for (int j = 0; j < 4; ++j) {
                     float a0 = __fmul_rn(v[k][j].x, w[k][j]);
                     float a1 = __fmul_rn(v[k][j].y, w[k][j]);
-                    a0 = dpp_add_xor1(a0); a1 = dpp_add_xor1(a1);
-                    a0 = dpp_add_xor2(a0); a1 = dpp_add_xor2(a1);
-                    a0 = dpp_add_half_mirror(a0); a1 = dpp_add_half_mirror(a1);
+                    dpp_sum8_pair(a0, a1);
                     if (corner == 0) {
                         float *o = s_out + (wave * 32 + j * 8 + sub) * E + hoff + 2 * lvl[k];
                         o[0] = a0;
@@ -467,9 +471,7 @@ __global__ __launch_bounds__(kThreadsS) void encode_fwd_f2_zorder_kernel(HmLevel
                 for (int j = 0; j < 4; ++j) {
                     float a0 = __fmul_rn(v[kk][j].x, w[kk][j]);
                     float a1 = __fmul_rn(v[kk][j].y, w[kk][j]);
-                    a0 = dpp_add_xor1(a0); a1 = dpp_add_xor1(a1);
-                    a0 = dpp_add_xor2(a0); a1 = dpp_add_xor2(a1);
-                    a0 = dpp_add_half_mirror(a0); a1 = dpp_add_half_mirror(a1);
+                    dpp_sum8_pair(a0, a1);
                     if (corner == 0) {
                         float *o = s_out + (wave * 32 + j * 8 + sub) * ES + hoff + 2 * lvl[kk];
                         o[0] = a0;
