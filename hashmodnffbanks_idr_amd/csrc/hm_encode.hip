@@ -422,7 +422,11 @@ __global__ __launch_bounds__(kThreadsS) void encode_fwd_f2_zorder_kernel(HmLevel
         __syncthreads();
         if (ES > E && tid < kTileS)
             for (int c = E; c < ES; ++c) s_out[tid * ES + c] = 0.0f;
+#ifdef HM_ENC_DIAG_NOFOURIER
+        if (false) {
+#else
         if (fourier) {
+#endif
             const int p = tid & (kTileS - 1);
             const int cg = tid / kTileS;  // 0..1
             const float x0 = s_x[p * 3 + 0], x1 = s_x[p * 3 + 1], x2 = s_x[p * 3 + 2];
@@ -449,6 +453,12 @@ __global__ __launch_bounds__(kThreadsS) void encode_fwd_f2_zorder_kernel(HmLevel
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const int l = min(lvl[kk], L - 1);
+#ifdef HM_ENC_DIAG_LMIN   // scripts/gather_level_probe.py: the kernel's time with only some of the levels gathered
+                if (lvl[kk] < HM_ENC_DIAG_LMIN || lvl[kk] > HM_ENC_DIAG_LMAX) {
+                    for (int j = 0; j < 4; ++j) { v[kk][j] = make_float2(0.0f, 0.0f); w[kk][j] = 0.0f; }
+                    continue;
+                }
+#endif
                 const int32_t res = lv.res[l];
                 const uint32_t rows = lv.rows[l], magic = lv.magic[l];
                 const float2 *tl = table + lv.row_off[l];
@@ -467,6 +477,9 @@ __global__ __launch_bounds__(kThreadsS) void encode_fwd_f2_zorder_kernel(HmLevel
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 if (lvl[kk] >= L) continue;
+#ifdef HM_ENC_DIAG_LMIN
+                if (lvl[kk] < HM_ENC_DIAG_LMIN || lvl[kk] > HM_ENC_DIAG_LMAX) continue;
+#endif
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float a0 = __fmul_rn(v[kk][j].x, w[kk][j]);
@@ -485,6 +498,9 @@ __global__ __launch_bounds__(kThreadsS) void encode_fwd_f2_zorder_kernel(HmLevel
         // floats >= ES, 16-byte aligned base: ops.encode_fwd allocates big outputs that way) ONE dwordx4 instruction of
         // ES/4 lanes writes a whole row - the 32-byte sectors of the row leave the CU together instead of as the three
         // partial-line stores of the dword path (WRITE_SIZE 1.44x the output bytes, profiles/r02_gather_pmc.json)
+#ifdef HM_ENC_DIAG_NOSTORE
+        if (s_out[tid] == 12345.678f)     // (never: the rows are computed but not written)
+#endif
         if (((out_stride & 3) == 0) && out_stride >= ES && (reinterpret_cast<uintptr_t>(out) & 15u) == 0) {
             const int nv = ES >> 2;                       // float4 per row (17 at E = 67)
             const int rows_per_wave = 64 / nv;            // 3
